@@ -1,0 +1,185 @@
+/*
+ * rtx.h — C ABI of librtx.so: the MI355X (gfx950) implementation of the
+ * per-pixel tracer hot path of antoinedesbois/Ray-Tracer-Rust.
+ *
+ * The reference has no FFI or plugin interface.  The seam
+ * this library replaces is the body of the thread fan-out in render(),
+ * src/main.rs:275-303: everything between "have a Scene and the random-sample
+ * table" and "have a filled RGB8 image", i.e. render_pixel() (src/main.rs:180-240)
+ * applied to every pixel, with the src/tracer tree underneath.  A Rust caller binds
+ * these entry points with an `extern "C"` block.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every input/output host buffer is owned
+ *     by the caller and may be freed as soon as the call returns;
+ *   - RtxScene is an opaque library-owned handle; device memory never escapes,
+ *     except through the *_device entry point, which writes into a device
+ *     buffer the caller owns;
+ *   - every function returns RTX_OK (0) or a negative RtxError; nothing throws
+ *     or aborts across the boundary (the reference's convention is
+ *     unwrap()-panic, src/main.rs:291,297,302,313-315 — not carried over);
+ *   - rtx_scene_create/destroy are not re-entrant per handle; rendering on
+ *     DISTINCT devices may run concurrently from distinct host threads on one
+ *     scene (mirrors one-thread-per-slice, src/main.rs:275-299); same-device
+ *     calls are serialised internally;
+ *   - there is no CPU fallback: rendering without a usable HIP device fails
+ *     with RTX_ERR_NO_DEVICE.
+ *
+ * Pixel/row conventions follow the reference: px is the column, py the row,
+ * byte offset of a pixel in an RGB8 frame = (py*width + px)*3
+ * (put_pixel(px,py), src/main.rs:293-294).
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1
+
+typedef enum RtxError {
+    RTX_OK              =  0,
+    RTX_ERR_BAD_ARG     = -1,  /* null pointer, zero size, row range outside the frame ...        */
+    RTX_ERR_NO_DEVICE   = -2,  /* no HIP device / device index out of range                       */
+    RTX_ERR_HIP         = -3,  /* a HIP runtime call failed (rtx_last_hip_error() has the code)   */
+    RTX_ERR_OOM         = -4,  /* host or device allocation failed                                */
+    RTX_ERR_UNSUPPORTED = -5,  /* e.g. non-finite geometry                                        */
+    RTX_ERR_INTERNAL    = -6,
+    RTX_ERR_IO          = -7   /* host helpers: file not found / parse error                      */
+} RtxError;
+
+/* acceleration structure used for closest-hit (results are identical) */
+#define RTX_ACCEL_BVH    0u  /* SAH BVH over the triangles' AABBs, wave-uniform traversal (default) */
+#define RTX_ACCEL_BRUTE  1u  /* one leaf holding every triangle: brute-force scan                    */
+
+/*
+ * Flat description of the reference's Scene (src/tracer/utils/scene.rs:6-12):
+ *   width,height           Scene.width/height
+ *   eye,u,v,w,distance     Camera after Camera::new (camera.rs:17-35); rtxh_camera_new computes u,v,w
+ *   light_v0..2            vertices of Light.primitives[0] (light.rs:11-13 samples only that one)
+ *   v0v1v2, rgb            the Vec<Primitive> handed to BoundingVolumeHierarchy::new, in that order
+ *                          (Triangle arm: v0,v1,v2 + Color); the library derives e1, e2, normal
+ *                          with Triangle::new's operation order (triangle.rs:22-34)
+ *   tie_rank               optional, n_tris entries: position of each triangle in the left-to-right
+ *                          leaf order of the reference BVH.  When two triangles are hit at exactly
+ *                          the same distance the reference returns the right-most one
+ *                          (bounding_volume_hierarchy.rs:123-130); the library returns the one with
+ *                          the larger tie_rank.  NULL = rank is the index.  rtxh_ref_leaf_rank
+ *                          computes it (restates bounding_volume_hierarchy.rs:173-226).
+ *   nb_ray,nb_light_sample NB_RAY / NB_LIGHT_SAMPLE (src/main.rs:38-39)
+ *   samples,n_samples      the random-sample table, n_samples pairs (s.0,s.1) interleaved
+ *                          (src/main.rs:253,262-265); NB_RAND_SAMPLE = 2,000,000 in the reference
+ */
+typedef struct RtxSceneDesc {
+    uint32_t width, height;
+    float eye[3], u[3], v[3], w[3];
+    float distance;
+    float light_v0[3], light_v1[3], light_v2[3];
+    uint32_t n_tris;
+    const float *v0v1v2;        /* n_tris x 9 */
+    const float *rgb;           /* n_tris x 3 */
+    const uint32_t *tie_rank;   /* n_tris, or NULL */
+    uint32_t nb_ray, nb_light_sample;
+    const float *samples;       /* n_samples x 2 */
+    uint32_t n_samples;
+    uint32_t accel;             /* RTX_ACCEL_* */
+    uint32_t leaf_max;          /* max triangles per BVH leaf; 0 = library default */
+} RtxSceneDesc;
+
+typedef struct RtxStats {
+    uint64_t primary_rays;      /* pixels rendered x nb_ray                                     */
+    uint64_t primary_hits;      /* primary rays with a closest hit                              */
+    uint64_t shadow_rays;       /* nb_light_sample x primary_hits                               */
+    uint64_t rays;              /* R_total = primary_rays + shadow_rays                         */
+    uint64_t box_tests;         /* ray-box slab tests executed (per lane)                       */
+    uint64_t tri_tests;         /* ray-triangle Möller–Trumbore tests executed (per lane)       */
+    uint64_t wave_node_visits;  /* BVH node records fetched (per wave)                          */
+    uint64_t wave_tri_visits;   /* triangle records fetched (per wave)                          */
+    double   kernel_ms;         /* hipEvent time of the kernel(s) of this call                  */
+    double   total_ms;          /* host wall time of the call (launch + D2H + gather)           */
+} RtxStats;
+
+typedef struct RtxSceneInfo {
+    uint32_t n_tris, n_nodes, n_leaves, max_leaf_tris, depth;
+    uint32_t n_light_points;
+    uint64_t node_bytes, tri_bytes, shade_bytes, sample_bytes;
+} RtxSceneInfo;
+
+typedef struct RtxScene RtxScene;
+
+/* ---- device path --------------------------------------------------------- */
+
+int rtx_abi_version(void);
+/* number of usable HIP devices (0 when there is none; never negative) */
+int rtx_device_count(void);
+
+/* Host-side preparation only (no device is touched): copies the inputs, derives e1/e2/normal,
+ * the 100 light points, the gamma threshold table and the acceleration structure. */
+int rtx_scene_create(const RtxSceneDesc *desc, RtxScene **out);
+void rtx_scene_destroy(RtxScene *scene);
+int rtx_scene_info(const RtxScene *scene, RtxSceneInfo *info);
+
+/* Upload the prepared scene to `device` (idempotent; rendering does it on first use). */
+int rtx_scene_upload(RtxScene *scene, int device);
+
+/* Render rows [row0,row0+nrows) on `device` into out_rgb (nrows*width*3 bytes, host).
+ * stats may be NULL; when non-NULL the launch also counts tests (slightly slower). */
+int rtx_render_rows(RtxScene *scene, int device, uint32_t row0, uint32_t nrows,
+                    uint8_t *out_rgb, RtxStats *stats);
+
+/* Whole frame, row tiles of `tile_rows` rows dealt round-robin to devices[0..n_devices)
+ * (tile t -> devices[t % n_devices]); out_rgb is height*width*3 bytes, host. */
+int rtx_render_frame(RtxScene *scene, const int *devices, int n_devices, uint32_t tile_rows,
+                     uint8_t *out_rgb, RtxStats *stats);
+
+/* Device-resident variant for callers that own device memory and a stream (one process per GPU):
+ * renders row tiles first_tile, first_tile+tile_stride, ... (tile t = rows [t*tile_rows,
+ * (t+1)*tile_rows) clipped to the frame) and packs them one after another into d_out_rgb
+ * (device pointer, d_out_bytes >= rtx_tiles_bytes(...)).  The launch is asynchronous on
+ * `stream` (a hipStream_t; NULL = the default stream); inputs must already be uploaded or are
+ * uploaded synchronously first.  d_counters: NULL, or a device buffer of 8 uint64 that the kernel
+ * ADDS its counters to (primary_hits, box_tests, tri_tests, wave_node_visits, wave_tri_visits). */
+int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, uint32_t tile_stride,
+                            uint32_t tile_rows, void *d_out_rgb, size_t d_out_bytes,
+                            void *stream, uint64_t *d_counters);
+/* rows / bytes the call above produces */
+uint32_t rtx_tiles_rows(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows);
+size_t   rtx_tiles_bytes(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows);
+
+const char *rtx_strerror(int err);
+int rtx_last_hip_error(void);
+
+/* ---- prepared-scene read-back (host logic tests, no device needed) --------- */
+/* out: n_light_points x 3 floats — Light::get_sample(T[(r*nb_ray+i) % n]) (src/main.rs:194-196) */
+int rtx_scene_light_points(const RtxScene *scene, float *out);
+/* out: 256 floats; byte value of a linear channel x = number of thresholds b>=1 with thr[b] <= x */
+int rtx_scene_gamma_thresholds(const RtxScene *scene, float *out256);
+/* out: n_tris x 3 unit normals in input order (Triangle::new, triangle.rs:29) */
+int rtx_scene_normals(const RtxScene *scene, float *out);
+/* the traversal stream: node records (8 dwords each) and the triangle order of the leaves */
+int rtx_scene_nodes(const RtxScene *scene, uint32_t *out_dwords /* n_nodes*8 */, uint32_t *out_tri_order /* n_tris */);
+
+/* ---- host helpers: the caller side of the seam, restated (rtxh_*) ---------- */
+/* Camera::new, src/tracer/utils/camera.rs:17-35 */
+void rtxh_camera_new(const float eye[3], const float look_at[3], const float up[3],
+                     float u[3], float v[3], float w[3]);
+/* import_obj, src/main.rs:114-149: returns the triangle count (>= 0) and a malloc'ed n x 9 array
+ * in *v0v1v2 (free with rtxh_free), or a negative RtxError. */
+int  rtxh_import_obj(const char *path, float **v0v1v2);
+void rtxh_free(void *p);
+/* rank of each primitive in the left-to-right leaf order of BoundingVolumeHierarchy::new
+ * (bounding_volume_hierarchy.rs:173-226; O(n^2)): out_rank[i] for triangle i. */
+int  rtxh_ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank);
+/* seeded stand-in for the thread_rng table (src/main.rs:260-265): splitmix64, 24-bit floats */
+void rtxh_gen_samples(uint64_t seed, uint32_t n_pairs, float *out);
+/* RGB8 PNG (what img.save(.., image::PNG) produces on decode, src/main.rs:313-315) */
+int  rtxh_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

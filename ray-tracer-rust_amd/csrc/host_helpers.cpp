@@ -1,0 +1,204 @@
+// host_helpers.cpp — rtxh_* entry points: the caller side of the seam, restated so that a host
+// program (or the Rust shim in INTEGRATION.md) can assemble an RtxSceneDesc the way the
+// reference's main() assembles its Scene.  Pure host code; citations are path:line in the
+// reference repository.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "scene_prep.h"
+
+namespace {
+
+// --- PNG (RGB8, stored deflate blocks: no compression library needed) ---------------
+uint32_t crc_table[256];
+bool crc_ready = false;
+
+void crc_init()
+{
+    for (uint32_t n = 0; n < 256; ++n) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        crc_table[n] = c;
+    }
+    crc_ready = true;
+}
+
+uint32_t crc_update(uint32_t crc, const uint8_t *p, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) crc = crc_table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return crc;
+}
+
+void put_be32(std::vector<uint8_t> &v, uint32_t x)
+{
+    v.push_back(uint8_t(x >> 24)); v.push_back(uint8_t(x >> 16)); v.push_back(uint8_t(x >> 8)); v.push_back(uint8_t(x));
+}
+
+void put_chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data)
+{
+    put_be32(png, static_cast<uint32_t>(data.size()));
+    const size_t start = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), data.begin(), data.end());
+    const uint32_t crc = crc_update(0xFFFFFFFFu, png.data() + start, png.size() - start) ^ 0xFFFFFFFFu;
+    put_be32(png, crc);
+}
+
+std::vector<std::string> split_on_space(const std::string &line)
+{
+    // Rust's str::split(" "): every single space separates, empty tokens are kept
+    std::vector<std::string> tok;
+    size_t start = 0;
+    for (;;) {
+        const size_t sp = line.find(' ', start);
+        if (sp == std::string::npos) { tok.push_back(line.substr(start)); break; }
+        tok.push_back(line.substr(start, sp - start));
+        start = sp + 1;
+    }
+    return tok;
+}
+
+bool parse_f32(const std::string &s, float &out)
+{
+    if (s.empty()) return false;
+    char *end = nullptr;
+    out = std::strtof(s.c_str(), &end);
+    return end && *end == '\0';
+}
+
+bool parse_index(const std::string &s, size_t &out)
+{
+    if (s.empty() || s[0] == '-' || s[0] == '+') return false;
+    char *end = nullptr;
+    const unsigned long long v = std::strtoull(s.c_str(), &end, 10);
+    out = static_cast<size_t>(v);
+    return end && *end == '\0';
+}
+
+}  // namespace
+
+extern "C" {
+
+void rtxh_camera_new(const float eye[3], const float look_at[3], const float up[3],
+                     float u[3], float v[3], float w[3])
+{
+    rtx::camera_new(eye, look_at, up, u, v, w);
+}
+
+// import_obj — src/main.rs:114-149.  Only "v x y z" and "f i j k" lines mean anything; face
+// indices are 1-based into the vertices read so far.  Where the reference would panic
+// (unparsable number, index out of range, fewer than four tokens) this returns RTX_ERR_IO.
+int rtxh_import_obj(const char *path, float **v0v1v2)
+{
+    if (!path || !v0v1v2) return RTX_ERR_BAD_ARG;
+    *v0v1v2 = nullptr;
+    std::ifstream in(path);
+    if (!in) return RTX_ERR_IO;
+    std::vector<float> verts, tris;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();   // BufRead::lines strips "\r\n" too
+        const std::vector<std::string> tok = split_on_space(line);
+        if (tok[0] == "v") {                                         // :130-136
+            if (tok.size() < 4) return RTX_ERR_IO;
+            float xyz[3];
+            for (int k = 0; k < 3; ++k)
+                if (!parse_f32(tok[1 + k], xyz[k])) return RTX_ERR_IO;
+            verts.insert(verts.end(), xyz, xyz + 3);
+        } else if (tok[0] == "f") {                                  // :137-145
+            if (tok.size() < 4) return RTX_ERR_IO;
+            for (int k = 0; k < 3; ++k) {
+                size_t id;
+                if (!parse_index(tok[1 + k], id) || id < 1 || id > verts.size() / 3) return RTX_ERR_IO;
+                tris.insert(tris.end(), verts.begin() + 3 * (id - 1), verts.begin() + 3 * id);
+            }
+        }
+    }
+    const size_t n = tris.size() / 9;
+    if (n > 0x3FFFFFFFu) return RTX_ERR_UNSUPPORTED;
+    float *out = static_cast<float *>(std::malloc(n ? tris.size() * sizeof(float) : sizeof(float)));
+    if (!out) return RTX_ERR_OOM;
+    if (n) std::memcpy(out, tris.data(), tris.size() * sizeof(float));
+    *v0v1v2 = out;
+    return static_cast<int>(n);
+}
+
+void rtxh_free(void *p) { std::free(p); }
+
+int rtxh_ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank)
+{
+    try {
+        return rtx::ref_leaf_rank(n_tris, v0v1v2, out_rank);
+    } catch (...) {
+        return RTX_ERR_OOM;
+    }
+}
+
+// Deterministic stand-in for the table the reference fills from thread_rng (src/main.rs:260-265):
+// splitmix64; each draw keeps the top 24 bits of the high word, f = bits * 2^-24 in [0,1)
+// (the 24-bit construction rand 0.3 uses for f32); entry = (s.0, s.1) in draw order.
+void rtxh_gen_samples(uint64_t seed, uint32_t n_pairs, float *out)
+{
+    uint64_t state = seed;
+    const uint64_t total = 2ull * n_pairs;
+    for (uint64_t i = 0; i < total; ++i) {
+        state += 0x9E3779B97F4A7C15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        out[i] = static_cast<float>(static_cast<uint32_t>(z >> 40)) * (1.0f / 16777216.0f);
+    }
+}
+
+int rtxh_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb)
+{
+    if (!path || !rgb || !width || !height) return RTX_ERR_BAD_ARG;
+    if (!crc_ready) crc_init();
+    try {
+        std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+        std::vector<uint8_t> ihdr;
+        put_be32(ihdr, width);
+        put_be32(ihdr, height);
+        const uint8_t tail[5] = {8, 2, 0, 0, 0};   // 8-bit, truecolour, deflate, no filter, no interlace
+        ihdr.insert(ihdr.end(), tail, tail + 5);
+        put_chunk(png, "IHDR", ihdr);
+
+        // raw scanlines: filter byte 0 + row
+        const size_t row = static_cast<size_t>(width) * 3u;
+        std::vector<uint8_t> raw;
+        raw.reserve((row + 1) * height);
+        for (uint32_t y = 0; y < height; ++y) {
+            raw.push_back(0);
+            raw.insert(raw.end(), rgb + y * row, rgb + (y + 1) * row);
+        }
+        std::vector<uint8_t> z = {0x78, 0x01};
+        uint32_t a = 1, b = 0;   // adler32
+        size_t pos = 0;
+        while (pos < raw.size()) {
+            const size_t n = std::min<size_t>(65535, raw.size() - pos);
+            z.push_back(pos + n == raw.size() ? 1 : 0);
+            z.push_back(uint8_t(n)); z.push_back(uint8_t(n >> 8));
+            z.push_back(uint8_t(~n)); z.push_back(uint8_t((~n) >> 8));
+            z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+            for (size_t i = 0; i < n; ++i) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+            pos += n;
+        }
+        put_be32(z, (b << 16) | a);
+        put_chunk(png, "IDAT", z);
+        put_chunk(png, "IEND", {});
+        FILE *f = std::fopen(path, "wb");
+        if (!f) return RTX_ERR_IO;
+        const bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+        return (std::fclose(f) == 0 && ok) ? RTX_OK : RTX_ERR_IO;
+    } catch (...) {
+        return RTX_ERR_OOM;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,455 @@
+// rtx_api.cpp — the C ABI of librtx.so (include/rtx.h): scene handles, uploads, launches, gathers.
+//
+// Stands where the thread fan-out of the reference's render() stands (src/main.rs:275-303):
+// the caller has a Scene and a sample table, and gets back RGB8 rows.  No CPU rendering path
+// exists in this library; without a HIP device every render entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+#include "scene_prep.h"
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+#define RTX_HIP(call)                                 \
+    do {                                              \
+        hipError_t e_ = (call);                       \
+        if (e_ != hipSuccess) {                       \
+            g_last_hip_error = static_cast<int>(e_);  \
+            return e_ == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP; \
+        }                                             \
+    } while (0)
+
+struct DeviceState {
+    std::mutex mu;
+    bool uploaded = false;
+    void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t *d_out = nullptr;
+    size_t d_out_cap = 0;
+    unsigned long long *d_counters = nullptr;
+    uint8_t *h_stage = nullptr;   // pinned
+    size_t h_stage_cap = 0;
+};
+
+// restores the caller's current device on scope exit
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int dev) { ok_ = hipGetDevice(&prev_) == hipSuccess; err_ = hipSetDevice(dev); }
+    ~DeviceGuard() { if (ok_) (void)hipSetDevice(prev_); }
+    hipError_t status() const { return err_; }
+private:
+    int prev_ = 0;
+    bool ok_ = false;
+    hipError_t err_ = hipSuccess;
+};
+
+double wall_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct RtxScene {
+    rtx::PreparedScene prep;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<DeviceState>> dev;
+};
+
+namespace {
+
+int device_count_quiet()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+int get_state(RtxScene *scene, int device, DeviceState **out)
+{
+    if (device < 0 || device >= device_count_quiet()) return RTX_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(scene->mu);
+    auto &slot = scene->dev[device];
+    if (!slot) slot.reset(new (std::nothrow) DeviceState);
+    if (!slot) return RTX_ERR_OOM;
+    *out = slot.get();
+    return RTX_OK;
+}
+
+template <class T>
+int upload_vec(void **dst, const std::vector<T> &v)
+{
+    const size_t bytes = v.size() * sizeof(T);
+    RTX_HIP(hipMalloc(dst, bytes ? bytes : 16));
+    if (bytes) RTX_HIP(hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
+    return RTX_OK;
+}
+
+// caller holds st.mu and has the device current
+int ensure_uploaded(RtxScene *scene, DeviceState &st)
+{
+    if (st.uploaded) return RTX_OK;
+    const rtx::PreparedScene &p = scene->prep;
+    int rc;
+    if ((rc = upload_vec(&st.nodes, p.nodes)) != RTX_OK) return rc;
+    if ((rc = upload_vec(&st.tris, p.tris)) != RTX_OK) return rc;
+    if ((rc = upload_vec(&st.shade, p.shade)) != RTX_OK) return rc;
+    if ((rc = upload_vec(&st.samples, p.samples)) != RTX_OK) return rc;
+    if ((rc = upload_vec(&st.lights, p.light_points)) != RTX_OK) return rc;
+    RTX_HIP(hipMalloc(&st.thr, sizeof(p.gamma_thr)));
+    RTX_HIP(hipMemcpy(st.thr, p.gamma_thr, sizeof(p.gamma_thr), hipMemcpyHostToDevice));
+    RTX_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_counters), rtx::kNumCounters * sizeof(unsigned long long)));
+    RTX_HIP(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    RTX_HIP(hipEventCreate(&st.ev0));
+    RTX_HIP(hipEventCreate(&st.ev1));
+    st.uploaded = true;
+    return RTX_OK;
+}
+
+rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
+{
+    const rtx::PreparedScene &p = scene->prep;
+    rtx::DeviceScene S;
+    S.nodes = static_cast<const rtx::NodeRec *>(st.nodes);
+    S.tris = static_cast<const rtx::TriRec *>(st.tris);
+    S.shade = static_cast<const rtx::ShadeRec *>(st.shade);
+    S.samples = static_cast<const float2 *>(st.samples);
+    S.light_points = static_cast<const float *>(st.lights);
+    S.gamma_thr = static_cast<const float *>(st.thr);
+    S.n_nodes = static_cast<uint32_t>(p.nodes.size());
+    S.n_samples = p.n_samples;
+    S.width = p.width;
+    S.height = p.height;
+    S.nb_ray = p.nb_ray;
+    S.nb_light = p.nb_light_sample;
+    std::memcpy(S.eye, p.eye, 12);
+    std::memcpy(S.cu, p.cam_u, 12);
+    std::memcpy(S.cv, p.cam_v, 12);
+    std::memcpy(S.cw, p.cam_w, 12);
+    S.distance = p.distance;
+    return S;
+}
+
+int ensure_out(DeviceState &st, size_t bytes, bool need_stage)
+{
+    if (st.d_out_cap < bytes) {
+        if (st.d_out) RTX_HIP(hipFree(st.d_out));
+        st.d_out = nullptr;
+        st.d_out_cap = 0;
+        RTX_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_out), bytes));
+        st.d_out_cap = bytes;
+    }
+    if (need_stage && st.h_stage_cap < bytes) {
+        if (st.h_stage) RTX_HIP(hipHostFree(st.h_stage));
+        st.h_stage = nullptr;
+        st.h_stage_cap = 0;
+        RTX_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.h_stage), bytes, hipHostMallocDefault));
+        st.h_stage_cap = bytes;
+    }
+    return RTX_OK;
+}
+
+uint32_t tiles_rows(uint32_t height, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows)
+{
+    if (!tile_rows || !tile_stride) return 0;
+    uint64_t rows = 0;
+    for (uint64_t t = first_tile; t * tile_rows < height; t += tile_stride) {
+        const uint64_t r0 = t * tile_rows;
+        rows += (height - r0 < tile_rows) ? (height - r0) : tile_rows;
+    }
+    return static_cast<uint32_t>(rows);
+}
+
+void fill_stats(RtxStats *s, const RtxScene *scene, uint64_t pixels, const unsigned long long *c,
+                double kernel_ms, double total_ms)
+{
+    std::memset(s, 0, sizeof *s);
+    s->primary_rays = pixels * scene->prep.nb_ray;
+    s->primary_hits = c[0];
+    s->shadow_rays = c[0] * scene->prep.nb_light_sample;
+    s->rays = s->primary_rays + s->shadow_rays;
+    s->box_tests = c[1];
+    s->tri_tests = c[2];
+    s->wave_node_visits = c[3];
+    s->wave_tri_visits = c[4];
+    s->kernel_ms = kernel_ms;
+    s->total_ms = total_ms;
+}
+
+// launch one device's share; caller holds st.mu and has the device current
+int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool count, bool stage)
+{
+    int rc = ensure_uploaded(scene, st);
+    if (rc != RTX_OK) return rc;
+    const size_t bytes = static_cast<size_t>(ts.local_rows) * scene->prep.width * 3u;
+    if ((rc = ensure_out(st, bytes ? bytes : 16, stage)) != RTX_OK) return rc;
+    if (count)
+        RTX_HIP(hipMemsetAsync(st.d_counters, 0, rtx::kNumCounters * sizeof(unsigned long long), st.stream));
+    RTX_HIP(hipEventRecord(st.ev0, st.stream));
+    RTX_HIP(rtx::launch_trace_shade(device_scene(scene, st), ts, st.d_out, count ? st.d_counters : nullptr, st.stream));
+    RTX_HIP(hipEventRecord(st.ev1, st.stream));
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_abi_version(void) { return RTX_ABI_VERSION; }
+
+int rtx_device_count(void) { return device_count_quiet(); }
+
+int rtx_last_hip_error(void) { return g_last_hip_error; }
+
+const char *rtx_strerror(int err)
+{
+    switch (err) {
+    case RTX_OK: return "ok";
+    case RTX_ERR_BAD_ARG: return "bad argument";
+    case RTX_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case RTX_ERR_HIP: return "HIP runtime error";
+    case RTX_ERR_OOM: return "out of memory";
+    case RTX_ERR_UNSUPPORTED: return "unsupported input";
+    case RTX_ERR_INTERNAL: return "internal error";
+    case RTX_ERR_IO: return "I/O or parse error";
+    default: return "unknown error";
+    }
+}
+
+int rtx_scene_create(const RtxSceneDesc *desc, RtxScene **out)
+{
+    if (!desc || !out) return RTX_ERR_BAD_ARG;
+    *out = nullptr;
+    RtxScene *s = new (std::nothrow) RtxScene;
+    if (!s) return RTX_ERR_OOM;
+    int rc;
+    try {
+        rc = rtx::prepare_scene(*desc, s->prep);
+    } catch (...) {
+        rc = RTX_ERR_INTERNAL;
+    }
+    if (rc != RTX_OK) { delete s; return rc; }
+    *out = s;
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(RtxScene *scene)
+{
+    if (!scene) return;
+    for (auto &kv : scene->dev) {
+        DeviceState &st = *kv.second;
+        DeviceGuard g(kv.first);
+        if (g.status() != hipSuccess) continue;
+        if (st.stream) (void)hipStreamSynchronize(st.stream);
+        void *bufs[] = {st.nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters};
+        for (void *b : bufs) if (b) (void)hipFree(b);
+        if (st.h_stage) (void)hipHostFree(st.h_stage);
+        if (st.ev0) (void)hipEventDestroy(st.ev0);
+        if (st.ev1) (void)hipEventDestroy(st.ev1);
+        if (st.stream) (void)hipStreamDestroy(st.stream);
+    }
+    delete scene;
+}
+
+int rtx_scene_info(const RtxScene *scene, RtxSceneInfo *info)
+{
+    if (!scene || !info) return RTX_ERR_BAD_ARG;
+    const rtx::PreparedScene &p = scene->prep;
+    info->n_tris = p.n_tris;
+    info->n_nodes = static_cast<uint32_t>(p.nodes.size());
+    info->n_leaves = p.n_leaves;
+    info->max_leaf_tris = p.max_leaf_tris;
+    info->depth = p.depth;
+    info->n_light_points = p.nb_ray * p.nb_light_sample;
+    info->node_bytes = p.nodes.size() * sizeof(rtx::NodeRec);
+    info->tri_bytes = p.tris.size() * sizeof(rtx::TriRec);
+    info->shade_bytes = p.shade.size() * sizeof(rtx::ShadeRec);
+    info->sample_bytes = p.samples.size() * sizeof(float);
+    return RTX_OK;
+}
+
+int rtx_scene_upload(RtxScene *scene, int device)
+{
+    if (!scene) return RTX_ERR_BAD_ARG;
+    DeviceState *st;
+    int rc = get_state(scene, device, &st);
+    if (rc != RTX_OK) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    DeviceGuard g(device);
+    RTX_HIP(g.status());
+    return ensure_uploaded(scene, *st);
+}
+
+int rtx_render_rows(RtxScene *scene, int device, uint32_t row0, uint32_t nrows, uint8_t *out_rgb, RtxStats *stats)
+{
+    if (!scene || !out_rgb) return RTX_ERR_BAD_ARG;
+    const uint32_t H = scene->prep.height, W = scene->prep.width;
+    if (row0 > H || nrows > H - row0) return RTX_ERR_BAD_ARG;
+    const double t0 = wall_ms();
+    DeviceState *st;
+    int rc = get_state(scene, device, &st);
+    if (rc != RTX_OK) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    DeviceGuard g(device);
+    RTX_HIP(g.status());
+    if (nrows == 0) {
+        unsigned long long zero[rtx::kNumCounters] = {0};
+        if (stats) fill_stats(stats, scene, 0, zero, 0.0, wall_ms() - t0);
+        return RTX_OK;
+    }
+    const rtx::TileSpec ts{row0, nrows, nrows, nrows};
+    if ((rc = launch_on(scene, *st, ts, stats != nullptr, false)) != RTX_OK) return rc;
+    const size_t bytes = static_cast<size_t>(nrows) * W * 3u;
+    RTX_HIP(hipMemcpyAsync(out_rgb, st->d_out, bytes, hipMemcpyDeviceToHost, st->stream));
+    unsigned long long c[rtx::kNumCounters] = {0};
+    if (stats)
+        RTX_HIP(hipMemcpyAsync(c, st->d_counters, sizeof c, hipMemcpyDeviceToHost, st->stream));
+    RTX_HIP(hipStreamSynchronize(st->stream));
+    if (stats) {
+        float ms = 0.0f;
+        RTX_HIP(hipEventElapsedTime(&ms, st->ev0, st->ev1));
+        fill_stats(stats, scene, static_cast<uint64_t>(nrows) * W, c, ms, wall_ms() - t0);
+    }
+    return RTX_OK;
+}
+
+int rtx_render_frame(RtxScene *scene, const int *devices, int n_devices, uint32_t tile_rows,
+                     uint8_t *out_rgb, RtxStats *stats)
+{
+    if (!scene || !devices || n_devices <= 0 || !tile_rows || !out_rgb) return RTX_ERR_BAD_ARG;
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = a + 1; b < n_devices; ++b)
+            if (devices[a] == devices[b]) return RTX_ERR_BAD_ARG;
+    const uint32_t H = scene->prep.height, W = scene->prep.width;
+    const size_t row_bytes = static_cast<size_t>(W) * 3u;
+    const double t0 = wall_ms();
+    std::vector<DeviceState *> sts(n_devices, nullptr);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    std::vector<rtx::TileSpec> specs(n_devices);
+    for (int j = 0; j < n_devices; ++j) {
+        int rc = get_state(scene, devices[j], &sts[j]);
+        if (rc != RTX_OK) return rc;
+        locks.emplace_back(sts[j]->mu);
+    }
+    // launch everywhere first (asynchronous), then gather
+    for (int j = 0; j < n_devices; ++j) {
+        const uint32_t rows = tiles_rows(H, static_cast<uint32_t>(j), static_cast<uint32_t>(n_devices), tile_rows);
+        specs[j] = rtx::TileSpec{static_cast<uint32_t>(j) * tile_rows, tile_rows,
+                                 static_cast<uint32_t>(n_devices) * tile_rows, rows};
+        if (!rows) continue;
+        DeviceGuard g(devices[j]);
+        RTX_HIP(g.status());
+        int rc = launch_on(scene, *sts[j], specs[j], stats != nullptr, true);
+        if (rc != RTX_OK) return rc;
+        RTX_HIP(hipMemcpyAsync(sts[j]->h_stage, sts[j]->d_out, rows * row_bytes, hipMemcpyDeviceToHost, sts[j]->stream));
+    }
+    unsigned long long total[rtx::kNumCounters] = {0};
+    double kernel_ms = 0.0;
+    for (int j = 0; j < n_devices; ++j) {
+        if (!specs[j].local_rows) continue;
+        DeviceGuard g(devices[j]);
+        RTX_HIP(g.status());
+        unsigned long long c[rtx::kNumCounters] = {0};
+        if (stats)
+            RTX_HIP(hipMemcpyAsync(c, sts[j]->d_counters, sizeof c, hipMemcpyDeviceToHost, sts[j]->stream));
+        RTX_HIP(hipStreamSynchronize(sts[j]->stream));
+        // scatter the packed tiles of this device into the frame (disjoint rows per device)
+        uint32_t ly = 0;
+        for (uint64_t t = static_cast<uint64_t>(j); t * tile_rows < H; t += static_cast<uint64_t>(n_devices)) {
+            const uint32_t r0 = static_cast<uint32_t>(t * tile_rows);
+            const uint32_t n = (H - r0 < tile_rows) ? H - r0 : tile_rows;
+            std::memcpy(out_rgb + r0 * row_bytes, sts[j]->h_stage + ly * row_bytes, n * row_bytes);
+            ly += n;
+        }
+        if (stats) {
+            float ms = 0.0f;
+            RTX_HIP(hipEventElapsedTime(&ms, sts[j]->ev0, sts[j]->ev1));
+            if (ms > kernel_ms) kernel_ms = ms;
+            for (int k = 0; k < rtx::kNumCounters; ++k) total[k] += c[k];
+        }
+    }
+    if (stats) fill_stats(stats, scene, static_cast<uint64_t>(H) * W, total, kernel_ms, wall_ms() - t0);
+    return RTX_OK;
+}
+
+uint32_t rtx_tiles_rows(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows)
+{
+    return scene ? tiles_rows(scene->prep.height, first_tile, tile_stride, tile_rows) : 0;
+}
+
+size_t rtx_tiles_bytes(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows)
+{
+    return scene ? static_cast<size_t>(tiles_rows(scene->prep.height, first_tile, tile_stride, tile_rows)) *
+                       scene->prep.width * 3u
+                 : 0;
+}
+
+int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, uint32_t tile_stride,
+                            uint32_t tile_rows, void *d_out_rgb, size_t d_out_bytes, void *stream,
+                            uint64_t *d_counters)
+{
+    if (!scene || !d_out_rgb || !tile_rows || !tile_stride) return RTX_ERR_BAD_ARG;
+    const uint32_t rows = tiles_rows(scene->prep.height, first_tile, tile_stride, tile_rows);
+    if (static_cast<size_t>(rows) * scene->prep.width * 3u > d_out_bytes) return RTX_ERR_BAD_ARG;
+    if (static_cast<uint64_t>(first_tile) * tile_rows > 0xFFFFFFFFull ||
+        static_cast<uint64_t>(tile_stride) * tile_rows > 0xFFFFFFFFull) return RTX_ERR_BAD_ARG;
+    DeviceState *st;
+    int rc = get_state(scene, device, &st);
+    if (rc != RTX_OK) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    DeviceGuard g(device);
+    RTX_HIP(g.status());
+    if ((rc = ensure_uploaded(scene, *st)) != RTX_OK) return rc;
+    const rtx::TileSpec ts{first_tile * tile_rows, tile_rows, tile_stride * tile_rows, rows};
+    RTX_HIP(rtx::launch_trace_shade(device_scene(scene, *st), ts, static_cast<uint8_t *>(d_out_rgb),
+                                    reinterpret_cast<unsigned long long *>(d_counters),
+                                    static_cast<hipStream_t>(stream)));
+    return RTX_OK;
+}
+
+int rtx_scene_light_points(const RtxScene *scene, float *out)
+{
+    if (!scene || !out) return RTX_ERR_BAD_ARG;
+    std::memcpy(out, scene->prep.light_points.data(), scene->prep.light_points.size() * sizeof(float));
+    return RTX_OK;
+}
+
+int rtx_scene_gamma_thresholds(const RtxScene *scene, float *out256)
+{
+    if (!scene || !out256) return RTX_ERR_BAD_ARG;
+    std::memcpy(out256, scene->prep.gamma_thr, sizeof scene->prep.gamma_thr);
+    return RTX_OK;
+}
+
+int rtx_scene_normals(const RtxScene *scene, float *out)
+{
+    if (!scene || !out) return RTX_ERR_BAD_ARG;
+    for (size_t i = 0; i < scene->prep.shade.size(); ++i) std::memcpy(out + 3 * i, scene->prep.shade[i].normal, 12);
+    return RTX_OK;
+}
+
+int rtx_scene_nodes(const RtxScene *scene, uint32_t *out_dwords, uint32_t *out_tri_order)
+{
+    if (!scene) return RTX_ERR_BAD_ARG;
+    if (out_dwords)
+        std::memcpy(out_dwords, scene->prep.nodes.data(), scene->prep.nodes.size() * sizeof(rtx::NodeRec));
+    if (out_tri_order)
+        for (size_t i = 0; i < scene->prep.tris.size(); ++i) out_tri_order[i] = scene->prep.tris[i].idx;
+    return RTX_OK;
+}
+
+}  // extern "C"

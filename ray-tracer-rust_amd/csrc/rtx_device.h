@@ -1,0 +1,44 @@
+// rtx_device.h — kernel argument blocks and the launcher, shared by rtx_kernel.hip and rtx_api.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "scene_prep.h"
+
+namespace rtx {
+
+// Everything the kernel reads, resident in HBM for the life of the upload.
+// Passed by value (kernarg segment -> SGPRs).
+struct DeviceScene {
+    const NodeRec  *nodes;         // n_nodes x 32 B, pre-order with skip links
+    const TriRec   *tris;          // n_tris x 64 B, leaf order
+    const ShadeRec *shade;         // n_tris x 32 B, caller order
+    const float2   *samples;       // n_samples x (s.0, s.1)
+    const float    *light_points;  // nb_ray x nb_light x 3
+    const float    *gamma_thr;     // 256
+    uint32_t n_nodes, n_samples;
+    uint32_t width, height;
+    uint32_t nb_ray, nb_light;
+    float eye[3], cu[3], cv[3], cw[3];
+    float distance;
+};
+
+// Which rows a launch renders: local row ly (0 <= ly < local_rows) is row
+//   first_row + (ly / tile_rows) * tile_stride_rows + ly % tile_rows
+// of the frame and row ly of the (packed) output buffer.
+struct TileSpec {
+    uint32_t first_row;
+    uint32_t tile_rows;
+    uint32_t tile_stride_rows;
+    uint32_t local_rows;
+};
+
+// counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits
+constexpr int kNumCounters = 8;
+
+hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
+                              unsigned long long *d_counters, hipStream_t stream);
+
+}  // namespace rtx

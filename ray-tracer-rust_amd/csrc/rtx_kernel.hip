@@ -1,0 +1,258 @@
+// rtx_kernel.hip — the per-pixel tracer as one HIP kernel for gfx950 (MI355X, CDNA4).
+//
+// Replaces render_pixel() + everything below it in the reference
+// (src/main.rs:151-240, src/tracer/**); citations are path:line in that repository.
+//
+// Mapping
+//   one work-item per pixel; a 64-lane wavefront owns an 8x8 pixel tile, a 256-thread
+//   workgroup four such tiles side by side (32x8 pixels).
+//
+// Closest hit (BVHNode::intersect, bounding_volume_hierarchy.rs:50-143)
+//   The acceleration structure is a pre-order, skip-linked BVH stream (scene_prep.h).  A
+//   wavefront walks it as ONE traversal: the node index lives in a scalar register, node and
+//   triangle records arrive through scalar (SMEM) loads and are consumed as SGPR operands, and
+//   the 64 lanes test their own rays against the same box / triangle.  A subtree is skipped
+//   only when NO lane's box test passes (wave ballot), so control flow never diverges and no
+//   per-lane stack exists.  Lanes apply the reference's leaf rule themselves: a triangle hit
+//   counts only if the ray also passes that triangle's own AABB (bvh.rs:52) and t >= 1.0
+//   (bvh.rs:64-67).  Because the reference never prunes by distance, every node whose box
+//   passes is visited here too; the result is the minimum over the same candidate set.
+//
+// Arithmetic
+//   IEEE binary32, one rounding per operation, in the reference's operation order; compiled
+//   with -ffp-contract=off and correctly rounded division / square root (hipcc default).
+//   The gamma curve is not evaluated on the device: scene_prep locates the 255 byte steps of
+//   (x.powf(1/2.2)*255) as u8 with the host libm and the kernel counts thresholds <= x.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "rtx_device.h"
+
+namespace rtx {
+
+#define RTX_CONSTANT __attribute__((address_space(4)))
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct WaveCounters {
+    unsigned long long box_tests = 0, tri_tests = 0, node_visits = 0, tri_visits = 0;
+};
+
+// BoundingBox::intersect as a predicate — bounding_box.rs:99-181.  Branch-free restatement:
+// the early `return None`s become masks, the values computed after them are unused there.
+__device__ __forceinline__ bool slab_exact(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                           float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const bool inside = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;   // :104-108
+    const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
+    float tmin = ((px ? lox : hix) - ox) / dx;                                                   // :120-127
+    float tmax = ((px ? hix : lox) - ox) / dx;
+    const float tymin = ((py ? loy : hiy) - oy) / dy;                                            // :129-136
+    const float tymax = ((py ? hiy : loy) - oy) / dy;
+    const bool miss_xy = tmin > tymax || tymin > tmax;                                           // :138-140
+    tmin = tymin > tmin ? tymin : tmin;                                                          // :142-144
+    tmax = tymax < tmax ? tymax : tmax;                                                          // :146-148
+    const float tzmin = ((pz ? loz : hiz) - oz) / dz;                                            // :150-157
+    const float tzmax = ((pz ? hiz : loz) - oz) / dz;
+    const bool miss_z = tmin > tzmax || tzmin > tmax;                                            // :159-161
+    tmin = tzmin > tmin ? tzmin : tmin;                                                          // :163-165
+    tmax = tzmax < tmax ? tzmax : tmax;                                                          // :167-169
+    const bool ok = tmin < FLT_MAX && tmax > 0.0f;                                               // :171
+    return inside || (!miss_xy && !miss_z && ok);
+}
+
+// One wave-uniform closest-hit traversal.  `active` lanes carry a ray; the others never vote.
+// best_t / best_idx: minimum accepted distance and the caller-order index of its triangle.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                            const TriRec RTX_CONSTANT *__restrict__ tris,
+                                            const ShadeRec *__restrict__ shade, uint32_t n_nodes,
+                                            bool active, float ox, float oy, float oz,
+                                            float dx, float dy, float dz,
+                                            float &best_t, uint32_t &best_idx, WaveCounters &wc)
+{
+    best_t = __builtin_inff();
+    best_idx = kNone;
+    unsigned long long n_active = 0;
+    if (COUNT) n_active = __popcll(__ballot(active));
+
+    uint32_t i = 0;
+    while (i < n_nodes) {
+        const NodeRec RTX_CONSTANT *nd = nodes + i;
+        const float lox = nd->bmin[0], loy = nd->bmin[1], loz = nd->bmin[2];
+        const float hix = nd->bmax[0], hiy = nd->bmax[1], hiz = nd->bmax[2];
+        const uint32_t link = nd->link, info = nd->info;
+        const bool pass = active && slab_exact(lox, loy, loz, hix, hiy, hiz, ox, oy, oz, dx, dy, dz);
+        const bool any = __ballot(pass) != 0ull;
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+        const bool leaf = (info & kLeafFlag) != 0u;
+        if (!leaf) {
+            i = any ? i + 1u : link;
+            continue;
+        }
+        i = i + 1u;
+        if (!any) continue;
+        const uint32_t first = info & ~kLeafFlag;
+        for (uint32_t k = 0; k < link; ++k) {
+            const TriRec RTX_CONSTANT *tr = tris + (first + k);
+            const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
+            const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
+            const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
+            if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+            // Triangle::intersect — triangle.rs:66-94
+            const float pvx = dy * e2z - dz * e2y;                                   // :69
+            const float pvy = dz * e2x - dx * e2z;
+            const float pvz = dx * e2y - dy * e2x;
+            const float det = e1x * pvx + e1y * pvy + e1z * pvz;                     // :70
+            const bool parallel = det < 0.00001f && det > -0.00001f;                 // :73
+            const float inv = 1.0f / det;                                            // :77
+            const float tvx = ox - v0x, tvy = oy - v0y, tvz = oz - v0z;              // :78
+            const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;               // :79
+            const bool out_u = u < 0.0f || u > 1.0f;                                 // :80
+            const float qvx = tvy * e1z - tvz * e1y;                                 // :84
+            const float qvy = tvz * e1x - tvx * e1z;
+            const float qvz = tvx * e1y - tvy * e1x;
+            const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;                  // :85
+            const bool out_v = v < 0.0f || u + v > 1.0f;                             // :86
+            const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;               // :92
+            const bool some = !parallel && !out_u && !out_v;
+            // leaf rule: x < 1.0 -> None (bvh.rs:64-67)
+            if (active && some && !(t < 1.0f)) {
+                // the leaf's own box gates the triangle test in the reference (bvh.rs:52)
+                if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
+                               ox, oy, oz, dx, dy, dz)) {
+                    const uint32_t idx = tr->idx;
+                    bool take = t < best_t;
+                    if (!take && t == best_t && best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
+                        take = shade[idx].rank > shade[best_idx].rank;
+                    if (take) { best_t = t; best_idx = idx; }
+                }
+            }
+        }
+    }
+}
+
+// byte of a linear channel: number of thresholds (b >= 1) that are <= x  (color.rs:28-33)
+__device__ __forceinline__ uint32_t quantise(const float *__restrict__ thr, float x)
+{
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t step = 128; step; step >>= 1)
+        if (x >= thr[b + step]) b += step;
+    return b;
+}
+
+}  // namespace
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) trace_shade_kernel(DeviceScene S, TileSpec ts, uint8_t *__restrict__ out,
+                                                           unsigned long long *__restrict__ counters)
+{
+    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    const float RTX_CONSTANT *lights = (const float RTX_CONSTANT *)S.light_points;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+    // heavy rows (ground, bottom of the frame) are dispatched first
+    const uint32_t ly = (gridDim.y - 1u - blockIdx.y) * 8u + (lane >> 3);
+    const uint32_t tile = ly / ts.tile_rows;
+    const uint32_t py = ts.first_row + tile * ts.tile_stride_rows + (ly - tile * ts.tile_rows);
+    const bool in_frame = px < S.width && ly < ts.local_rows && py < S.height;
+
+    WaveCounters wc;
+    unsigned long long primary_hits = 0;
+
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;                                  // main.rs:182
+    const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
+    for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
+        // create_rays — main.rs:151-178
+        float s0 = 0.0f, s1 = 0.0f;
+        if (in_frame) {
+            const uint32_t k = (px * S.width + py + r) % S.n_samples;                // :162,165 (u32)
+            const float2 s = S.samples[k];
+            s0 = s.x;
+            s1 = s.y;
+        }
+        const float a = (float)px - (float)S.width / 2.0f + s0;                      // :161-162
+        const float b = (float)py - (float)S.height / 2.0f + s1;                     // :164-165
+        const float rx = (a * S.cu[0] + b * S.cv[0]) - S.distance * S.cw[0];         // :160-167
+        const float ry = (a * S.cu[1] + b * S.cv[1]) - S.distance * S.cw[1];
+        const float rz = (a * S.cu[2] + b * S.cv[2]) - S.distance * S.cw[2];
+        const float rn = sqrtf(rx * rx + ry * ry + rz * rz);                         // Ray::new, ray.rs:15
+        const float dx = rx / rn, dy = ry / rn, dz = rz / rn;
+
+        float t;
+        uint32_t idx;
+        closest_hit<COUNT>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1], S.eye[2],
+                           dx, dy, dz, t, idx, wc);                                   // main.rs:187
+        const bool hit = in_frame && idx != kNone;
+        const unsigned long long hit_mask = __ballot(hit);
+        if (hit_mask == 0ull) continue;                                               // main.rs:235
+        if (COUNT) primary_hits += __popcll(hit_mask);
+
+        float hx = 0.0f, hy = 0.0f, hz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        if (hit) {
+            hx = S.eye[0] + t * dx;                                                   // bvh.rs:69
+            hy = S.eye[1] + t * dy;
+            hz = S.eye[2] + t * dz;
+            const ShadeRec sh = S.shade[idx];
+            nx = sh.normal[0]; ny = sh.normal[1]; nz = sh.normal[2];                  // main.rs:206
+            cr = sh.rgb[0]; cg = sh.rgb[1]; cb = sh.rgb[2];                           // main.rs:191
+        }
+        for (uint32_t i = 0; i < S.nb_light; ++i) {                                   // main.rs:193
+            const float RTX_CONSTANT *lp = lights + 3u * (r * S.nb_light + i);        // main.rs:194-196 (hoisted)
+            const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;            // p - orig
+            const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);              // main.rs:202
+            const float sx = vx / dist_light, sy = vy / dist_light, sz = vz / dist_light;   // main.rs:201
+            float st;
+            uint32_t sidx;
+            closest_hit<COUNT>(nodes, tris, S.shade, S.n_nodes, hit, hx, hy, hz, sx, sy, sz, st, sidx, wc);  // main.rs:204
+            const float lnd = fabsf(nx * sx + ny * sy + nz * sz);                     // main.rs:207
+            bool lit = true;                                                          // main.rs:229-231
+            if (sidx != kNone) {                                                      // main.rs:219-227
+                const float qx = hx - (hx + st * sx), qy = hy - (hy + st * sy), qz = hz - (hz + st * sz);
+                lit = sqrtf(qx * qx + qy * qy + qz * qz) > dist_light;
+            }
+            if (hit && lit) {                                                         // main.rs:209-216
+                acc_r = acc_r + ((cr * lnd) / denom);
+                acc_g = acc_g + ((cg * lnd) / denom);
+                acc_b = acc_b + ((cb * lnd) / denom);
+            }
+        }
+    }
+
+    if (in_frame) {                                                                   // put_pixel, main.rs:293-294
+        uint8_t *p = out + ((size_t)ly * S.width + px) * 3u;
+        p[0] = (uint8_t)quantise(S.gamma_thr, acc_r);
+        p[1] = (uint8_t)quantise(S.gamma_thr, acc_g);
+        p[2] = (uint8_t)quantise(S.gamma_thr, acc_b);
+    }
+
+    if (COUNT && lane == 0 && counters) {
+        atomicAdd(&counters[0], primary_hits);
+        atomicAdd(&counters[1], wc.box_tests);
+        atomicAdd(&counters[2], wc.tri_tests);
+        atomicAdd(&counters[3], wc.node_visits);
+        atomicAdd(&counters[4], wc.tri_visits);
+    }
+}
+
+hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
+                              unsigned long long *d_counters, hipStream_t stream)
+{
+    if (ts.local_rows == 0) return hipSuccess;
+    const dim3 block(256);
+    const dim3 grid((S.width + 31u) / 32u, (ts.local_rows + 7u) / 8u);
+    if (d_counters)
+        hipLaunchKernelGGL(trace_shade_kernel<true>, grid, block, 0, stream, S, ts, d_out, d_counters);
+    else
+        hipLaunchKernelGGL(trace_shade_kernel<false>, grid, block, 0, stream, S, ts, d_out, d_counters);
+    return hipGetLastError();
+}
+
+}  // namespace rtx

@@ -1,0 +1,448 @@
+// scene_prep.cpp — host-side scene preparation (see scene_prep.h).
+//
+// Float arithmetic that feeds pixel values (camera basis, e1/e2/normal, light points)
+// follows the reference's operation order, one IEEE binary32 rounding per operation;
+// build with -ffp-contract=off.  Reference citations are path:line under the reference
+// repository (antoinedesbois/Ray-Tracer-Rust).
+#include "scene_prep.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace rtx {
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+inline V3 load3(const float *p) { return V3{p[0], p[1], p[2]}; }
+inline void store3(float *p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+// nalgebra 0.11 dot: accumulator starts at zero, terms added in x, y, z order
+inline float dot3(V3 a, V3 b)
+{
+    float acc = 0.0f;
+    acc = acc + a.x * b.x;
+    acc = acc + a.y * b.y;
+    acc = acc + a.z * b.z;
+    return acc;
+}
+inline V3 cross3(V3 a, V3 b)
+{
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Unit::new_normalize: divide each component by sqrt(dot(v,v))
+inline V3 unit3(V3 a)
+{
+    const float n = std::sqrt(dot3(a, a));
+    return V3{a.x / n, a.y / n, a.z / n};
+}
+
+inline float lesser(float a, float b) { return a < b ? a : b; }    // min_float, triangle.rs:37-39
+inline float greater(float a, float b) { return a < b ? b : a; }   // max_float, triangle.rs:41-43
+
+}  // namespace
+
+// Camera::new — src/tracer/utils/camera.rs:17-35
+void camera_new(const float eye[3], const float look_at[3], const float up[3],
+                float u[3], float v[3], float w[3])
+{
+    const V3 ww = unit3(load3(eye) - load3(look_at));
+    const V3 o = unit3(load3(up));
+    const V3 uu = unit3(cross3(o, ww));
+    const V3 vv = unit3(cross3(uu, ww));
+    store3(u, uu);
+    store3(v, vv);
+    store3(w, ww);
+}
+
+// Triangle::new + get_bounding_box — src/tracer/primitives/triangle.rs:22-34, :45-56
+void triangle_derive(const float v0[3], const float v1[3], const float v2[3],
+                     float e1[3], float e2[3], float normal[3], float bmin[3], float bmax[3])
+{
+    const V3 a = load3(v0), b = load3(v1), c = load3(v2);
+    const V3 ea = b - a, eb = c - a;
+    store3(e1, ea);
+    store3(e2, eb);
+    store3(normal, unit3(cross3(ea, eb)));
+    for (int k = 0; k < 3; ++k) {
+        bmin[k] = lesser(lesser(v0[k], v1[k]), v2[k]);
+        bmax[k] = greater(greater(v0[k], v1[k]), v2[k]);
+    }
+}
+
+// Triangle::get_sample — triangle.rs:113-127.  The third weight is v*sqrt(u), as in the
+// reference (the weights do not sum to one); kept on purpose.
+void light_sample(const float v0[3], const float v1[3], const float v2[3], float u, float v, float out[3])
+{
+    const float su = std::sqrt(u);
+    const float sv = std::sqrt(v);
+    const float w0 = 1.0f - su;
+    const float w1 = su * (1.0f - sv);
+    const float w2 = v * su;
+    for (int k = 0; k < 3; ++k)
+        out[k] = w0 * v0[k] + w1 * v1[k] + w2 * v2[k];
+}
+
+// Color::to_rgba on one channel — src/tracer/utils/color.rs:10-13,28-33.
+// Rust's `as u8` truncates toward zero, saturates, and maps NaN to 0.
+uint8_t gamma_quantise(float linear)
+{
+    const float gamma = 2.2f;
+    const float enc = std::pow(linear, 1.0f / gamma) * 255.0f;
+    if (std::isnan(enc) || enc <= 0.0f) return 0;
+    if (enc >= 255.0f) return 255;
+    return static_cast<uint8_t>(enc);
+}
+
+// The kernel never evaluates powf: the byte of a channel is a step function of the f32
+// input, so the 255 step positions are located here with the host libm (the same powf
+// the reference's f32::powf resolves to) and the kernel counts thresholds <= x.
+// thr[b] (b >= 1) = smallest non-negative float x with gamma_quantise(x) >= b.
+int build_gamma_thresholds(float thr[256])
+{
+    auto as_float = [](uint32_t bits) { float f; std::memcpy(&f, &bits, 4); return f; };
+    const uint32_t hi_bits = 0x40000000u;  // 2.0f: quantises to 255
+    if (gamma_quantise(as_float(hi_bits)) != 255 || gamma_quantise(0.0f) != 0) return RTX_ERR_INTERNAL;
+    thr[0] = -std::numeric_limits<float>::infinity();
+    for (int b = 1; b < 256; ++b) {
+        uint32_t lo = 0, hi = hi_bits;   // q(lo) < b <= q(hi); positive floats order like their bit patterns
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (gamma_quantise(as_float(mid)) >= b) hi = mid; else lo = mid;
+        }
+        // the bisection assumed a clean step; verify it on the neighbourhood
+        for (uint32_t k = 1; k <= 256; ++k) {
+            if (hi >= k && gamma_quantise(as_float(hi - k)) >= b) return RTX_ERR_INTERNAL;
+            if (gamma_quantise(as_float(hi + k - 1)) < b) return RTX_ERR_INTERNAL;
+        }
+        thr[b] = as_float(hi);
+    }
+    for (int b = 2; b < 256; ++b)
+        if (!(thr[b] >= thr[b - 1])) return RTX_ERR_INTERNAL;
+    return RTX_OK;
+}
+
+// Leaf order of BoundingVolumeHierarchy::new — bounding_volume_hierarchy.rs:173-226.
+// Needed only to reproduce which of two exactly-equidistant triangles the reference
+// returns (the right-most leaf, :123-130).  Clusters by bbox *extent* because
+// get_center() returns max-min (bounding_box.rs:183-189); O(n^2) per level like the original.
+int ref_leaf_rank(uint32_t n, const float *v0v1v2, uint32_t *out_rank)
+{
+    if (!n || !v0v1v2 || !out_rank) return RTX_ERR_BAD_ARG;
+    struct Cluster { float lo[3], hi[3]; int32_t left, right; };   // left < 0: leaf
+    std::vector<Cluster> pool;
+    pool.reserve(2 * static_cast<size_t>(n));
+    std::vector<V3> extent;
+    extent.reserve(2 * static_cast<size_t>(n));
+    auto push_extent = [&](const Cluster &c) {
+        extent.push_back(V3{c.hi[0] - c.lo[0], c.hi[1] - c.lo[1], c.hi[2] - c.lo[2]});
+    };
+    std::vector<int32_t> level(n), next;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *t = v0v1v2 + 9 * static_cast<size_t>(i);
+        Cluster c;
+        for (int k = 0; k < 3; ++k) {
+            c.lo[k] = lesser(lesser(t[k], t[3 + k]), t[6 + k]);
+            c.hi[k] = greater(greater(t[k], t[3 + k]), t[6 + k]);
+        }
+        c.left = -1;
+        c.right = static_cast<int32_t>(i);   // leaf: right holds the primitive index
+        pool.push_back(c);
+        push_extent(c);
+        level[i] = static_cast<int32_t>(i);
+    }
+    while (level.size() > 1) {
+        next.clear();
+        while (level.size() > 1) {
+            const int32_t last = level.back();           // nodes.pop()
+            level.pop_back();
+            const V3 ref = extent[last];
+            float best = FLT_MAX;
+            size_t best_at = SIZE_MAX;
+            for (size_t i = 0; i < level.size(); ++i) {
+                const V3 d = ref - extent[level[i]];
+                const float dist = std::sqrt(dot3(d, d));
+                if (dist < best) { best = dist; best_at = i; }   // strict: first minimum wins
+            }
+            if (best_at == SIZE_MAX) return RTX_ERR_UNSUPPORTED;  // the reference would panic in swap_remove
+            const int32_t partner = level[best_at];      // swap_remove(best_at)
+            level[best_at] = level.back();
+            level.pop_back();
+            Cluster m;
+            const Cluster &a = pool[last], &b = pool[partner];   // BVHNode::new(left = last, right = closest)
+            for (int k = 0; k < 3; ++k) {                         // BoundingBox::new_from, bounding_box.rs:25-96
+                m.lo[k] = a.lo[k] < b.lo[k] ? a.lo[k] : b.lo[k];
+                m.hi[k] = a.hi[k] > b.hi[k] ? a.hi[k] : b.hi[k];
+            }
+            m.left = last;
+            m.right = partner;
+            next.push_back(static_cast<int32_t>(pool.size()));
+            pool.push_back(m);
+            push_extent(m);
+        }
+        if (level.size() == 1) next.push_back(level[0]);  // odd one out goes last
+        level.swap(next);
+    }
+    // left-to-right leaf walk, iterative
+    std::vector<int32_t> stack{level[0]};
+    uint32_t rank = 0;
+    while (!stack.empty()) {
+        const int32_t id = stack.back();
+        stack.pop_back();
+        const Cluster &c = pool[id];
+        if (c.left < 0) { out_rank[c.right] = rank++; continue; }
+        stack.push_back(c.right);
+        stack.push_back(c.left);
+    }
+    return rank == n ? RTX_OK : RTX_ERR_INTERNAL;
+}
+
+// --------------------------------------------------------------------------
+// Acceleration structure for the kernel: binned-SAH BVH over the triangles' exact
+// AABBs, flattened in pre-order with skip links.  Its shape is free: the reference
+// visits every node whose box test passes and counts a leaf only when the leaf's own
+// box passes, and IEEE subtraction/division are monotone, so a ray that passes a
+// triangle's box passes every box that contains it — any tree over the same leaf
+// boxes yields the same hit set (DESIGN.md "Why a different tree gives the same image").
+
+namespace {
+
+struct Prim {
+    float lo[3], hi[3];
+    float c[3];
+    uint32_t idx;
+};
+
+struct Box {
+    float lo[3], hi[3];
+    void reset()
+    {
+        for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+    }
+    void grow(const float l[3], const float h[3])
+    {
+        for (int k = 0; k < 3; ++k) {
+            if (l[k] < lo[k]) lo[k] = l[k];
+            if (h[k] > hi[k]) hi[k] = h[k];
+        }
+    }
+    double half_area() const
+    {
+        const double dx = double(hi[0]) - lo[0], dy = double(hi[1]) - lo[1], dz = double(hi[2]) - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+class TreeBuilder {
+public:
+    TreeBuilder(std::vector<Prim> &prims, std::vector<NodeRec> &nodes, uint32_t leaf_max, double box_cost)
+        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost) {}
+
+    uint32_t leaves = 0, max_leaf = 0, depth = 0;
+
+    void build(uint32_t begin, uint32_t end, uint32_t level)
+    {
+        if (level + 1 > depth) depth = level + 1;
+        const uint32_t count = end - begin;
+        Box bounds, cbounds;
+        bounds.reset();
+        cbounds.reset();
+        for (uint32_t i = begin; i < end; ++i) {
+            bounds.grow(prims_[i].lo, prims_[i].hi);
+            cbounds.grow(prims_[i].c, prims_[i].c);
+        }
+        const uint32_t self = static_cast<uint32_t>(nodes_.size());
+        NodeRec rec;
+        std::memcpy(rec.bmin, bounds.lo, 12);
+        std::memcpy(rec.bmax, bounds.hi, 12);
+        rec.link = 0;
+        rec.info = 0;
+        nodes_.push_back(rec);
+
+        uint32_t mid = 0;
+        bool split = count > 1 && choose_split(begin, end, bounds, cbounds, mid);
+        if (!split && count > leaf_max_) {        // coincident centroids: split by position in the list
+            mid = begin + count / 2;
+            split = true;
+        }
+        if (!split) {
+            nodes_[self].info = kLeafFlag | begin;
+            nodes_[self].link = count;
+            ++leaves;
+            if (count > max_leaf) max_leaf = count;
+            return;
+        }
+        build(begin, mid, level + 1);
+        build(mid, end, level + 1);
+        nodes_[self].link = static_cast<uint32_t>(nodes_.size());
+    }
+
+private:
+    static constexpr int kBins = 32;
+
+    bool choose_split(uint32_t begin, uint32_t end, const Box &bounds, const Box &cbounds, uint32_t &mid)
+    {
+        const uint32_t count = end - begin;
+        const double parent_area = bounds.half_area();
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            const double lo = cbounds.lo[axis], span = double(cbounds.hi[axis]) - lo;
+            if (!(span > 0)) continue;
+            Box bin_box[kBins];
+            uint32_t bin_n[kBins] = {0};
+            for (auto &b : bin_box) b.reset();
+            const double scale = kBins / span;
+            for (uint32_t i = begin; i < end; ++i) {
+                int b = static_cast<int>((prims_[i].c[axis] - lo) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                bin_box[b].grow(prims_[i].lo, prims_[i].hi);
+                ++bin_n[b];
+            }
+            double right_area[kBins];
+            uint32_t right_n[kBins];
+            Box acc;
+            acc.reset();
+            uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                if (bin_n[b]) acc.grow(bin_box[b].lo, bin_box[b].hi);
+                n += bin_n[b];
+                right_area[b] = n ? acc.half_area() : 0.0;
+                right_n[b] = n;
+            }
+            acc.reset();
+            n = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                if (bin_n[b]) acc.grow(bin_box[b].lo, bin_box[b].hi);
+                n += bin_n[b];
+                if (!n || !right_n[b + 1]) continue;
+                const double cost = acc.half_area() * n + right_area[b + 1] * right_n[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        if (best_axis < 0) return false;
+        if (count <= leaf_max_ && parent_area > 0) {
+            // SAH termination: a leaf costs count triangle tests; a split costs two box tests plus
+            // the children's expected triangle tests
+            const double split_cost = 2.0 * box_cost_ + best_cost / parent_area;
+            if (static_cast<double>(count) <= split_cost) return false;
+        }
+        const double lo = cbounds.lo[best_axis];
+        const double scale = kBins / (double(cbounds.hi[best_axis]) - lo);
+        auto it = std::partition(prims_.begin() + begin, prims_.begin() + end, [&](const Prim &p) {
+            int b = static_cast<int>((p.c[best_axis] - lo) * scale);
+            b = std::min(std::max(b, 0), kBins - 1);
+            return b <= best_bin;
+        });
+        mid = static_cast<uint32_t>(it - prims_.begin());
+        return mid > begin && mid < end;
+    }
+
+    std::vector<Prim> &prims_;
+    std::vector<NodeRec> &nodes_;
+    uint32_t leaf_max_;
+    double box_cost_;
+};
+
+}  // namespace
+
+int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
+{
+    if (!d.width || !d.height || !d.n_tris || !d.v0v1v2 || !d.rgb || !d.samples || !d.n_samples || !d.nb_ray)
+        return RTX_ERR_BAD_ARG;
+    if (d.n_tris >= 0x40000000u || d.accel > RTX_ACCEL_BRUTE) return RTX_ERR_BAD_ARG;
+    if (static_cast<uint64_t>(d.width) * d.height >= (1ull << 31)) return RTX_ERR_BAD_ARG;
+
+    s.width = d.width;
+    s.height = d.height;
+    std::memcpy(s.eye, d.eye, 12);
+    std::memcpy(s.cam_u, d.u, 12);
+    std::memcpy(s.cam_v, d.v, 12);
+    std::memcpy(s.cam_w, d.w, 12);
+    s.distance = d.distance;
+    s.nb_ray = d.nb_ray;
+    s.nb_light_sample = d.nb_light_sample;
+    s.n_tris = d.n_tris;
+    s.n_samples = d.n_samples;
+    try {
+        s.samples.assign(d.samples, d.samples + 2 * static_cast<size_t>(d.n_samples));
+
+        // light points: for ray r of a pixel and sample i the reference reads
+        // T[(r*NB_RAY + i) % len] (src/main.rs:194-196) — the same points for every pixel
+        s.light_points.resize(3 * static_cast<size_t>(d.nb_ray) * d.nb_light_sample);
+        for (uint32_t r = 0; r < d.nb_ray; ++r)
+            for (uint32_t i = 0; i < d.nb_light_sample; ++i) {
+                const size_t k = (static_cast<size_t>(r) * d.nb_ray + i) % d.n_samples;
+                light_sample(d.light_v0, d.light_v1, d.light_v2, d.samples[2 * k], d.samples[2 * k + 1],
+                             &s.light_points[3 * (static_cast<size_t>(r) * d.nb_light_sample + i)]);
+            }
+
+        const int grc = build_gamma_thresholds(s.gamma_thr);
+        if (grc != RTX_OK) return grc;
+
+        std::vector<Prim> prims(d.n_tris);
+        std::vector<TriRec> recs(d.n_tris);   // caller order for now
+        s.shade.resize(d.n_tris);
+        for (uint32_t i = 0; i < d.n_tris; ++i) {
+            const float *t = d.v0v1v2 + 9 * static_cast<size_t>(i);
+            for (int k = 0; k < 9; ++k)
+                if (!std::isfinite(t[k])) return RTX_ERR_UNSUPPORTED;
+            TriRec &r = recs[i];
+            ShadeRec &sh = s.shade[i];
+            std::memcpy(r.v0, t, 12);
+            triangle_derive(t, t + 3, t + 6, r.e1, r.e2, sh.normal, r.bmin, r.bmax);
+            r.idx = i;
+            std::memcpy(sh.rgb, d.rgb + 3 * static_cast<size_t>(i), 12);
+            sh.rank = d.tie_rank ? d.tie_rank[i] : i;
+            sh.pad = 0;
+            Prim &p = prims[i];
+            for (int k = 0; k < 3; ++k) {
+                p.lo[k] = r.bmin[k];
+                p.hi[k] = r.bmax[k];
+                p.c[k] = 0.5f * r.bmin[k] + 0.5f * r.bmax[k];
+            }
+            p.idx = i;
+        }
+
+        s.nodes.clear();
+        s.nodes.reserve(2 * static_cast<size_t>(d.n_tris));
+        if (d.accel == RTX_ACCEL_BRUTE) {
+            Box all;
+            all.reset();
+            for (const Prim &p : prims) all.grow(p.lo, p.hi);
+            NodeRec rec;
+            std::memcpy(rec.bmin, all.lo, 12);
+            std::memcpy(rec.bmax, all.hi, 12);
+            rec.info = kLeafFlag | 0u;
+            rec.link = d.n_tris;
+            s.nodes.push_back(rec);
+            s.n_leaves = 1;
+            s.max_leaf_tris = d.n_tris;
+            s.depth = 1;
+        } else {
+            uint32_t leaf_max = d.leaf_max ? d.leaf_max : 4;
+            double box_cost = 1.0;
+            if (const char *e = std::getenv("RTX_LEAF_MAX")) leaf_max = std::max(1, std::atoi(e));
+            if (const char *e = std::getenv("RTX_SAH_BOX_COST")) box_cost = std::atof(e);
+            TreeBuilder tb(prims, s.nodes, leaf_max, box_cost);
+            tb.build(0, d.n_tris, 0);
+            s.n_leaves = tb.leaves;
+            s.max_leaf_tris = tb.max_leaf;
+            s.depth = tb.depth;
+        }
+        s.tris.resize(d.n_tris);
+        for (uint32_t i = 0; i < d.n_tris; ++i) s.tris[i] = recs[prims[i].idx];
+    } catch (const std::bad_alloc &) {
+        return RTX_ERR_OOM;
+    }
+    return RTX_OK;
+}
+
+}  // namespace rtx

@@ -1,0 +1,84 @@
+// scene_prep.h — host-side preparation of a scene for the gfx950 tracer kernel.
+//
+// Pure C++ (no HIP): everything here runs on the CPU once per scene and is
+// testable without a device.  It is the host half of the product path, not a
+// fallback: nothing in this file traces a ray.
+//
+// Record layouts are shared with the kernel (rtx_kernel.hip includes this file).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rtx.h"
+
+namespace rtx {
+
+// One node of the threaded (pre-order, skip-linked) BVH stream: 8 dwords, fetched
+// by the kernel with one scalar 32-byte load.
+//   inner node : info = 0,            link = index of the node to continue with when the
+//                                     subtree is skipped (its first child is at index+1)
+//   leaf  node : info = 0x80000000|s, link = number of triangle records, s = first record
+struct NodeRec {
+    float    bmin[3];
+    uint32_t link;
+    float    bmax[3];
+    uint32_t info;
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+constexpr uint32_t kLeafFlag = 0x80000000u;
+
+// One triangle as the traversal consumes it: 16 dwords, one scalar 64-byte load.
+// v0,e1,e2 are the 36 bytes Möller–Trumbore reads (triangle.rs:66-94); bmin/bmax are the
+// triangle's own AABB (triangle.rs:45-56), needed because the reference only counts a leaf
+// whose box test passed (bounding_volume_hierarchy.rs:52); idx = index in the caller's order.
+struct TriRec {
+    float    v0[3];
+    float    e1[3];
+    float    e2[3];
+    float    bmin[3];
+    float    bmax[3];
+    uint32_t idx;
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+// Shading data of a triangle, indexed by the caller's triangle index (read once per hit).
+struct ShadeRec {
+    float    normal[3];   // Triangle::new, triangle.rs:29
+    uint32_t rank;        // tie rank (see RtxSceneDesc.tie_rank)
+    float    rgb[3];      // Color
+    uint32_t pad;
+};
+static_assert(sizeof(ShadeRec) == 32, "ShadeRec must be 32 bytes");
+
+struct PreparedScene {
+    uint32_t width = 0, height = 0;
+    float eye[3], cam_u[3], cam_v[3], cam_w[3];
+    float distance = 0;
+    uint32_t nb_ray = 1, nb_light_sample = 0;
+    uint32_t n_tris = 0;
+    uint32_t n_samples = 0;
+    std::vector<NodeRec>  nodes;
+    std::vector<TriRec>   tris;        // in leaf order
+    std::vector<ShadeRec> shade;       // in caller order
+    std::vector<float>    samples;     // n_samples x 2
+    std::vector<float>    light_points;// nb_ray x nb_light_sample x 3
+    float gamma_thr[256];
+    uint32_t n_leaves = 0, max_leaf_tris = 0, depth = 0;
+};
+
+// Returns RTX_OK or a negative RtxError.
+int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);
+
+// ---- pieces with their own tests ----
+void camera_new(const float eye[3], const float look_at[3], const float up[3],
+                float u[3], float v[3], float w[3]);
+void triangle_derive(const float v0[3], const float v1[3], const float v2[3],
+                     float e1[3], float e2[3], float normal[3], float bmin[3], float bmax[3]);
+void light_sample(const float v0[3], const float v1[3], const float v2[3], float u, float v, float out[3]);
+// byte = (x.powf(1/2.2) * 255.0) as u8 with the host libm — color.rs:10-13,28-33
+uint8_t gamma_quantise(float linear);
+int  build_gamma_thresholds(float thr[256]);
+int  ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank);
+
+}  // namespace rtx

@@ -1,0 +1,344 @@
+"""ctypes binding of librtx.so (include/rtx.h) — the Python face of the C ABI.
+
+Plumbing only: every ray is traced by the HIP kernel inside librtx.so.  There is
+no Python or CPU rendering path; if the library is missing, importing this
+module fails loudly, and rendering without a GPU raises RtxError(NO_DEVICE).
+
+Names mirror the reference (antoinedesbois/Ray-Tracer-Rust): Scene{width,height,
+light,camera,bvh} (src/tracer/utils/scene.rs:6-12) is flattened into
+RtxSceneDesc; the default-scene literals are those of main() (src/main.rs:327-358).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtx.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "librtx.so is not built (%s). Build it with: python -c 'import __graft_entry__ as g; g.build()' "
+        "or make -C ray-tracer-rust_amd/csrc" % LIB_PATH)
+
+_lib = C.CDLL(LIB_PATH)
+
+OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL, ERR_IO = 0, -1, -2, -3, -4, -5, -6, -7
+ACCEL_BVH, ACCEL_BRUTE = 0, 1
+
+# constants of the reference: src/main.rs:38-40
+NB_RAY, NB_LIGHT_SAMPLE, NB_RAND_SAMPLE = 1, 100, 2000000
+# default scene: camera src/main.rs:353-356, light :337-343, ground :102-111, frame :350-351
+DEFAULT_EYE = (0.0, 100.0, 200.0)
+DEFAULT_LOOK_AT = (0.0, 0.0, -100000.0)
+DEFAULT_UP = (0.0, 1.0, 0.0)
+DEFAULT_DISTANCE = 288.0
+DEFAULT_LIGHT = (-10.0, 300.0, -10.0, 10.0, 300.0, -10.0, 0.0, 300.0, 0.0)
+GROUND_TRI = (-10000.0, 0.0, -10000.0, 10000.0, 0.0, -10000.0, 0.0, 0.0, 10000.0)
+GROUND_RGB = (0.5, 0.5, 0.5)
+MESH_RGB = (1.0, 1.0, 1.0)
+DEFAULT_WIDTH, DEFAULT_HEIGHT = 1920, 1080
+DEFAULT_SEED = 20261004
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("eye", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+        ("distance", C.c_float),
+        ("light_v0", C.c_float * 3), ("light_v1", C.c_float * 3), ("light_v2", C.c_float * 3),
+        ("n_tris", C.c_uint32),
+        ("v0v1v2", f32p), ("rgb", f32p), ("tie_rank", u32p),
+        ("nb_ray", C.c_uint32), ("nb_light_sample", C.c_uint32),
+        ("samples", f32p), ("n_samples", C.c_uint32),
+        ("accel", C.c_uint32), ("leaf_max", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "primary_rays", "primary_hits", "shadow_rays", "rays", "box_tests", "tri_tests",
+        "wave_node_visits", "wave_tri_visits")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_tris", "n_nodes", "n_leaves", "max_leaf_tris", "depth", "n_light_points")] + \
+               [(n, C.c_uint64) for n in ("node_bytes", "tri_bytes", "shade_bytes", "sample_bytes")]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/rtx.h declares (tests check the export list against the header)
+_SIGS = {
+    "rtx_abi_version": (C.c_int, []),
+    "rtx_device_count": (C.c_int, []),
+    "rtx_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
+    "rtx_scene_destroy": (None, [C.c_void_p]),
+    "rtx_scene_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
+    "rtx_scene_upload": (C.c_int, [C.c_void_p, C.c_int]),
+    "rtx_render_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]),
+    "rtx_render_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_void_p, C.POINTER(Stats)]),
+    "rtx_render_tiles_device": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_size_t, C.c_void_p, C.c_void_p]),
+    "rtx_tiles_rows": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rtx_tiles_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rtx_strerror": (C.c_char_p, [C.c_int]),
+    "rtx_last_hip_error": (C.c_int, []),
+    "rtx_scene_light_points": (C.c_int, [C.c_void_p, f32p]),
+    "rtx_scene_gamma_thresholds": (C.c_int, [C.c_void_p, f32p]),
+    "rtx_scene_normals": (C.c_int, [C.c_void_p, f32p]),
+    "rtx_scene_nodes": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "rtxh_camera_new": (None, [f32p] * 6),
+    "rtxh_import_obj": (C.c_int, [C.c_char_p, C.POINTER(f32p)]),
+    "rtxh_free": (None, [C.c_void_p]),
+    "rtxh_ref_leaf_rank": (C.c_int, [C.c_uint32, f32p, u32p]),
+    "rtxh_gen_samples": (None, [C.c_uint64, C.c_uint32, f32p]),
+    "rtxh_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(_lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class RtxError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = _lib.rtx_strerror(code).decode()
+        if code == ERR_HIP:
+            msg += " (hipError %d)" % _lib.rtx_last_hip_error()
+        super().__init__("%s: %s [%d]" % (where, msg, code))
+
+
+def _check(code, where):
+    if code != OK:
+        raise RtxError(code, where)
+
+
+def _fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _f3(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(3))
+
+
+def abi_version():
+    return _lib.rtx_abi_version()
+
+
+def device_count():
+    return _lib.rtx_device_count()
+
+
+# ------------------------------------------------------------------ host helpers (rtxh_*)
+def camera_new(eye, look_at, up):
+    """Camera::new (src/tracer/utils/camera.rs:17-35) -> (u, v, w)."""
+    u, v, w = (np.zeros(3, np.float32) for _ in range(3))
+    _lib.rtxh_camera_new(_fp(_f3(eye)), _fp(_f3(look_at)), _fp(_f3(up)), _fp(u), _fp(v), _fp(w))
+    return u, v, w
+
+
+def import_obj(path):
+    """import_obj (src/main.rs:114-149) -> float32 [n, 9] (v0, v1, v2 per triangle)."""
+    p = f32p()
+    n = _lib.rtxh_import_obj(os.fsencode(path), C.byref(p))
+    if n < 0:
+        raise RtxError(n, "rtxh_import_obj(%s)" % path)
+    arr = np.ctypeslib.as_array(p, shape=(max(n, 1), 9))[:n].copy() if n else np.zeros((0, 9), np.float32)
+    _lib.rtxh_free(p)
+    return arr
+
+
+def ref_leaf_rank(tris):
+    tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+    out = np.zeros(len(tris), dtype=np.uint32)
+    _check(_lib.rtxh_ref_leaf_rank(len(tris), _fp(tris), out.ctypes.data_as(u32p)), "rtxh_ref_leaf_rank")
+    return out
+
+
+def gen_samples(seed=DEFAULT_SEED, n_pairs=NB_RAND_SAMPLE):
+    out = np.empty((n_pairs, 2), dtype=np.float32)
+    _lib.rtxh_gen_samples(seed, n_pairs, _fp(out))
+    return out
+
+
+def write_png(path, img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, c = img.shape
+    assert c == 3
+    _check(_lib.rtxh_write_png(os.fsencode(path), w, h, img.ctypes.data), "rtxh_write_png")
+
+
+def default_primitives(obj_paths):
+    """The primitive list main() builds: OBJ meshes in argv order, ground last (src/main.rs:327-335)."""
+    parts, cols = [], []
+    for p in obj_paths:
+        t = import_obj(p)
+        parts.append(t)
+        cols.append(np.tile(np.asarray(MESH_RGB, np.float32), (len(t), 1)))
+    parts.append(np.asarray(GROUND_TRI, np.float32).reshape(1, 9))
+    cols.append(np.asarray(GROUND_RGB, np.float32).reshape(1, 3))
+    return np.ascontiguousarray(np.concatenate(parts)), np.ascontiguousarray(np.concatenate(cols))
+
+
+# ------------------------------------------------------------------ Scene
+class Scene:
+    """Flattened Scene{width,height,light,camera,bvh}; owns an RtxScene handle."""
+
+    def __init__(self, width, height, tris, rgb, samples, *, eye=DEFAULT_EYE, look_at=DEFAULT_LOOK_AT,
+                 up=DEFAULT_UP, distance=DEFAULT_DISTANCE, light_tri=DEFAULT_LIGHT, nb_ray=NB_RAY,
+                 nb_light_sample=NB_LIGHT_SAMPLE, accel=ACCEL_BVH, leaf_max=0, tie_rank="reference"):
+        self._h = C.c_void_p()
+        self.width, self.height = int(width), int(height)
+        self.tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+        self.rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)
+        self.samples = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, 2)
+        if len(self.rgb) != len(self.tris):
+            raise ValueError("rgb and tris disagree")
+        if isinstance(tie_rank, str):
+            if tie_rank != "reference":
+                raise ValueError(tie_rank)
+            # BoundingVolumeHierarchy::new is O(n^2): only worth it where the reference itself could run
+            rank = ref_leaf_rank(self.tris) if len(self.tris) <= 50000 else None
+        else:
+            rank = None if tie_rank is None else np.ascontiguousarray(tie_rank, dtype=np.uint32)
+        self.tie_rank = rank
+        u, v, w = camera_new(eye, look_at, up)
+        lt = np.asarray(light_tri, dtype=np.float32).reshape(9)
+        d = SceneDesc()
+        d.width, d.height = self.width, self.height
+        d.eye[:] = _f3(eye).tolist()
+        d.u[:], d.v[:], d.w[:] = u.tolist(), v.tolist(), w.tolist()
+        d.distance = float(distance)
+        d.light_v0[:], d.light_v1[:], d.light_v2[:] = lt[0:3].tolist(), lt[3:6].tolist(), lt[6:9].tolist()
+        d.n_tris = len(self.tris)
+        d.v0v1v2, d.rgb = _fp(self.tris), _fp(self.rgb)
+        d.tie_rank = rank.ctypes.data_as(u32p) if rank is not None else None
+        d.nb_ray, d.nb_light_sample = int(nb_ray), int(nb_light_sample)
+        d.samples, d.n_samples = _fp(self.samples), len(self.samples)
+        d.accel, d.leaf_max = int(accel), int(leaf_max)
+        _check(_lib.rtx_scene_create(C.byref(d), C.byref(self._h)), "rtx_scene_create")
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            _lib.rtx_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- prepared-scene read-back
+    def info(self):
+        i = SceneInfo()
+        _check(_lib.rtx_scene_info(self._h, C.byref(i)), "rtx_scene_info")
+        return i.asdict()
+
+    def light_points(self):
+        n = self.info()["n_light_points"]
+        out = np.zeros((n, 3), np.float32)
+        _check(_lib.rtx_scene_light_points(self._h, _fp(out)), "rtx_scene_light_points")
+        return out
+
+    def gamma_thresholds(self):
+        out = np.zeros(256, np.float32)
+        _check(_lib.rtx_scene_gamma_thresholds(self._h, _fp(out)), "rtx_scene_gamma_thresholds")
+        return out
+
+    def normals(self):
+        out = np.zeros((len(self.tris), 3), np.float32)
+        _check(_lib.rtx_scene_normals(self._h, _fp(out)), "rtx_scene_normals")
+        return out
+
+    def nodes(self):
+        i = self.info()
+        nd = np.zeros((i["n_nodes"], 8), np.uint32)
+        order = np.zeros(i["n_tris"], np.uint32)
+        _check(_lib.rtx_scene_nodes(self._h, nd.ctypes.data_as(u32p), order.ctypes.data_as(u32p)), "rtx_scene_nodes")
+        return nd, order
+
+    # -- rendering (GPU only)
+    def upload(self, device=0):
+        _check(_lib.rtx_scene_upload(self._h, device), "rtx_scene_upload")
+
+    def render_rows(self, row0=0, nrows=None, device=0, stats=False):
+        if nrows is None:
+            nrows = self.height - row0
+        out = np.zeros((nrows, self.width, 3), np.uint8)
+        st = Stats()
+        _check(_lib.rtx_render_rows(self._h, device, row0, nrows, out.ctypes.data, C.byref(st) if stats else None),
+               "rtx_render_rows")
+        return (out, st.asdict()) if stats else out
+
+    def render_frame(self, devices=(0,), tile_rows=8, stats=False):
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        devs = (C.c_int * len(devices))(*devices)
+        st = Stats()
+        _check(_lib.rtx_render_frame(self._h, devs, len(devices), tile_rows, out.ctypes.data,
+                                     C.byref(st) if stats else None), "rtx_render_frame")
+        return (out, st.asdict()) if stats else out
+
+    def tiles_rows(self, first_tile, tile_stride, tile_rows):
+        return _lib.rtx_tiles_rows(self._h, first_tile, tile_stride, tile_rows)
+
+    def tiles_bytes(self, first_tile, tile_stride, tile_rows):
+        return _lib.rtx_tiles_bytes(self._h, first_tile, tile_stride, tile_rows)
+
+    def render_tiles_device(self, device, first_tile, tile_stride, tile_rows, d_out_ptr, d_out_bytes,
+                            stream=None, d_counters_ptr=None):
+        """Asynchronous launch into a device buffer the caller owns (e.g. a torch uint8 tensor)."""
+        _check(_lib.rtx_render_tiles_device(self._h, device, first_tile, tile_stride, tile_rows,
+                                            C.c_void_p(d_out_ptr), d_out_bytes,
+                                            C.c_void_p(stream) if stream else None,
+                                            C.c_void_p(d_counters_ptr) if d_counters_ptr else None),
+               "rtx_render_tiles_device")
+
+
+def default_scene(obj_paths, width=DEFAULT_WIDTH, height=DEFAULT_HEIGHT, samples=None, **kw):
+    """The scene main() renders (src/main.rs:319-362) for the given OBJ files."""
+    tris, rgb = default_primitives(obj_paths)
+    if samples is None:
+        samples = gen_samples()
+    return Scene(width, height, tris, rgb, samples, **kw)
+
+
+def tile_owner(tile, world_size):
+    """Row tile -> rank (interleaved): tile t belongs to rank t % world_size."""
+    return tile % world_size
+
+
+def scatter_tiles(frame, packed, first_tile, tile_stride, tile_rows):
+    """Place the packed rows of rtx_render_tiles_device back into a [H, W, 3] frame."""
+    h = frame.shape[0]
+    ly = 0
+    t = first_tile
+    while t * tile_rows < h:
+        r0 = t * tile_rows
+        n = min(tile_rows, h - r0)
+        frame[r0:r0 + n] = packed[ly:ly + n]
+        ly += n
+        t += tile_stride
+    return frame
