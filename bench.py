@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s + frame ms, big_bunny.obj @ 1920x1080 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU)
+
+A step = one whole frame of the hot path (primary rays + 100 shadow rays per hit pixel + gamma/RGB8
+store).  With N ranks the frame is split into row tiles dealt round-robin (tile t -> rank t % N,
+SURVEY.md §8(e)); there is no data-path collective, RCCL is used only for the barrier and for the
+max-over-ranks of the elapsed time.  Total work is fixed as N grows: "scaling": "strong".
+
+Inputs (triangles, BVH stream, sample table) are resident in HBM before the timed region; the
+output stays in HBM (torch tensor).  torch is plumbing here: device memory, stream, events,
+torch.distributed.  Every ray is traced by the HIP kernel behind the C ABI (include/rtx.h).
+
+One JSON line on stdout (rank 0).  Besides the contract fields:
+  roofline      dominant kernel (trace_shade_kernel) against the HBM roof, as the contract asks;
+                algorithmic bytes defined in DESIGN.md §Roofline.  The kernel is FP32-VALU bound
+                (the whole scene is L2-resident), so "roofline_valu" is printed next to it.
+  cpu_baseline  the CPU oracle in faithful-BVH mode (= the reference's src/tracer algorithm,
+                "port") timed on this box's host cores on a bounded sample of the same frame.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (first: its bundled HIP runtime must be the one in the process)
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[]; the metric is quoted on configs[2]
+    "c2": dict(desc="configs[1]: bunny.obj 1920x1080", objs=["bunny.obj"], width=1920, height=1080),
+    "c3": dict(desc="configs[2]: big_bunny.obj 1920x1080", objs=["big_bunny.obj"], width=1920, height=1080),
+    "c4": dict(desc="configs[3]: big_bunny.obj 4096x4096", objs=["big_bunny.obj"], width=4096, height=4096),
+    "c1b": dict(desc="big_bunny.obj 256x256 (test size)", objs=["big_bunny.obj"], width=256, height=256),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak (counts an FMA as 2 flop)
+FLOP_PER_TRI_TEST = 46         # full Möller–Trumbore path incl. the division
+FLOP_PER_BOX_TEST = 30         # 6 sub + 6 div + 18 compare/select
+BYTES_PER_TRI_REC = 36         # v0,e1,e2 consumed per test
+BYTES_PER_BOX_REC = 24         # bmin,bmax
+BYTES_PER_PIXEL_IO = 11        # 8 B of the sample table + 3 B framebuffer
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-png", default="")
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, samples_np, seconds, threads):
+    """Oracle (faithful BVH = the reference's algorithm) on row tiles spread over the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    if threads <= 0:
+        threads = min(16, os.cpu_count() or 1)
+    W, H = wl["width"], wl["height"]
+    sc = orclib.default_scene(wl["objs"], W, H, samples_np)
+    band = 2
+    n_bands = H // band
+    bits = max(1, (n_bands - 1).bit_length())
+    # bit-reversed band order: wherever the time budget stops it, the sample is spread evenly over the frame
+    order = sorted(range(n_bands), key=lambda b: int(format(b, "0%db" % bits)[::-1], 2))
+    rays, secs, rows = 0, 0.0, 0
+    for b in order:
+        t0 = time.perf_counter()
+        _, st = sc.render_rows(b * band, band, mode=orclib.MODE_BVH, nthreads=threads)
+        secs += time.perf_counter() - t0
+        rays += st["primary_rays"] + st["shadow_rays"]
+        rows += band
+        if secs >= seconds:
+            break
+    sc.close()
+    return {
+        "value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "%d of %d rows of the same frame (2-row bands in bit-reversed order, evenly spread), oracle "
+                  "faithful-BVH mode, %d threads, %.1f s, %d rays" % (rows, H, threads, secs, rays),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rtx = importlib.import_module("ray-tracer-rust_amd")
+    wl = WORKLOADS[args.workload]
+    W, H = wl["width"], wl["height"]
+    samples = rtx.gen_samples()
+    scene = rtx.default_scene([os.path.join(ROOT, "models", o) for o in wl["objs"]], W, H, samples)
+    info = scene.info()
+    scene.upload(local_rank)                               # inputs resident in HBM before timing
+
+    tile_rows = args.tile_rows
+    nbytes = scene.tiles_bytes(rank, world, tile_rows)
+    out = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(count=False):
+        scene.render_tiles_device(local_rank, rank, world, tile_rows, out.data_ptr(), nbytes,
+                                  stream.cuda_stream, counters.data_ptr() if count else None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # one counted launch (outside the timed region) gives the frame's ray / test counts
+    step(count=True)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+    c = counters.cpu().tolist()
+    primary_hits, box_tests, tri_tests, node_visits, tri_visits = c[0], c[1], c[2], c[3], c[4]
+    primary_rays = W * H * rtx.NB_RAY
+    r_total = primary_rays + rtx.NB_LIGHT_SAMPLE * primary_hits
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)   # this rank's launches
+    tt = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, kernel_s = tt.cpu().tolist()
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if args.save_png and world == 1:
+        frame = np.zeros((H, W, 3), np.uint8)
+        rtx.scatter_tiles(frame, out[:nbytes].cpu().numpy().reshape(-1, W, 3), rank, world, tile_rows)
+        rtx.write_png(args.save_png, frame)
+
+    if rank == 0:
+        mrays = r_total / (ms_per_step / 1e3) / 1e6
+        # roofline of the dominant kernel.  Per launch = per rank; counts are whole-frame sums, so divide by world.
+        alg_bytes = (tri_visits * BYTES_PER_TRI_REC + node_visits * BYTES_PER_BOX_REC + BYTES_PER_PIXEL_IO * W * H) / world
+        ach_gbs = alg_bytes / kernel_s / 1e9
+        flops = (tri_tests * FLOP_PER_TRI_TEST + box_tests * FLOP_PER_BOX_TEST) / world
+        ach_tf = flops / kernel_s / 1e12
+        # SURVEY §8(d) brute-force-equivalent HBM-level bytes (G = 256 rays share a staged record)
+        b_alg_brute = (-(-r_total // 256)) * info["n_tris"] * 36 + 11 * W * H
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch_n%d" % world)
+        line = {
+            "metric": "Mrays/sec + frame ms, big_bunny.obj @ 1920x1080" if args.workload == "c3"
+                      else "Mrays/sec + frame ms, " + wl["desc"],
+            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "reference asset models/%s + seeded sample table (splitmix64 seed %d); no dataset download"
+                    % (wl["objs"][0], rtx.DEFAULT_SEED),
+            "config": {"workload": wl["desc"] + ", 1 spp, 100 light samples, default scene of src/main.rs:327-358",
+                       "width": W, "height": H, "n_tris": info["n_tris"], "tile_rows": tile_rows,
+                       "partition": "row tiles, tile t -> rank t %% %d, no collective" % world,
+                       "accel": "sah-bvh leaf<=%d, %d nodes" % (info["max_leaf_tris"], info["n_nodes"])},
+            "frame_ms": round(ms_per_step, 4),
+            "rays_per_frame": r_total, "primary_hits": primary_hits,
+            "primary_mrays_per_s": round(primary_rays / (ms_per_step / 1e3) / 1e6, 3),
+            "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "trace_shade_kernel", "kernel_ms": round(kernel_s * 1e3, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "scene is L2-resident (%.2f MB): the kernel is FP32-VALU bound, see roofline_valu; "
+                                 "survey_b_alg_* = SURVEY 8(d) brute-force-equivalent bytes"
+                                 % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),
+                         "survey_b_alg_bytes": int(b_alg_brute),
+                         "survey_b_alg_frac": round(b_alg_brute / world / kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline_valu": {"bound": "fp32-valu", "achieved": round(ach_tf, 3), "peak": VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
+                              "box_tests": box_tests, "tri_tests": tri_tests,
+                              "wave_node_visits": node_visits, "wave_tri_visits": tri_visits},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl, samples, args.cpu_seconds, args.cpu_threads)
+            line["cpu_baseline"]["gpu_over_cpu"] = round(mrays / line["cpu_baseline"]["value"], 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

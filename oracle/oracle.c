@@ -600,15 +600,22 @@ typedef struct {
     pix_counters_t pc;
 } job_t;
 
+#define ORC_CHUNK 32u   /* pixels claimed at a time: keeps every thread busy even on 1-2 row requests */
+
 static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     const orc_scene *s = j->s;
+    const uint32_t chunks_per_row = (s->width + ORC_CHUNK - 1) / ORC_CHUNK;
+    const uint32_t n_chunks = chunks_per_row * j->nrows;
     for (;;) {
-        uint32_t r = __atomic_fetch_add(j->next_row, 1, __ATOMIC_RELAXED);
-        if (r >= j->nrows) break;
+        uint32_t ck = __atomic_fetch_add(j->next_row, 1, __ATOMIC_RELAXED);
+        if (ck >= n_chunks) break;
+        uint32_t r = ck / chunks_per_row;
+        uint32_t x0 = (ck % chunks_per_row) * ORC_CHUNK;
+        uint32_t x1 = x0 + ORC_CHUNK < s->width ? x0 + ORC_CHUNK : s->width;
         uint32_t py = j->row0 + r;
-        for (uint32_t px = 0; px < s->width; px++) {
+        for (uint32_t px = x0; px < x1; px++) {
             int32_t ft;
             v3 c = render_pixel(s, j->mode, px, py, &j->pc, &ft);
             size_t p = (size_t)r * s->width + px;

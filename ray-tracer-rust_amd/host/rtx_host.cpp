@@ -1,0 +1,83 @@
+// rtx_host — the reference's main() (src/main.rs:319-362) over the GPU path.
+//
+//   rtx_host [options] <obj>...        writes output.png like the reference
+//
+// Same scene assembly: OBJ meshes in argv order, ground last, the area light at y = 300, the
+// camera at (0,100,200) looking down -z with distance 288, 1920x1080 (src/main.rs:327-358).
+// Differences, all explicit: the sample table is seeded (the reference uses thread_rng), every
+// pixel is rendered (the reference drops len % (num_cpus-1) pixels), timing is in milliseconds
+// and the throughput counts all rays (the reference prints integer seconds and primary rays only,
+// src/main.rs:305-310).  Options exist because the reference hard-codes what they set.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tracer.hpp"
+
+using namespace tracer;
+
+int main(int argc, char **argv)
+{
+    uint32_t width = 1920, height = 1080, tile_rows = 8;
+    uint64_t seed = 20261004ull;
+    std::string out = "output.png";
+    std::vector<int> devices;
+    std::vector<std::string> objs;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&](const char *what) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--width") width = static_cast<uint32_t>(std::atoi(next("--width")));
+        else if (a == "--height") height = static_cast<uint32_t>(std::atoi(next("--height")));
+        else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 10);
+        else if (a == "--out") out = next("--out");
+        else if (a == "--tile-rows") tile_rows = static_cast<uint32_t>(std::atoi(next("--tile-rows")));
+        else if (a == "--devices") {
+            for (char *tok = std::strtok(const_cast<char *>(next("--devices")), ","); tok; tok = std::strtok(nullptr, ","))
+                devices.push_back(std::atoi(tok));
+        } else objs.push_back(a);
+    }
+    if (devices.empty()) devices.push_back(0);
+
+    std::printf("Building scene\n");                                          // main.rs:322
+    std::vector<primitives::Primitive> prims;
+    const auto ground = create_ground();                                      // main.rs:327
+    for (const std::string &path : objs) {                                    // main.rs:328-331
+        int err = RTX_OK;
+        auto mesh = import_obj(path, &err);
+        if (err != RTX_OK) std::printf("Not a valid path: %s\n", path.c_str());   // main.rs:118
+        prims.insert(prims.end(), mesh.begin(), mesh.end());
+    }
+    prims.insert(prims.end(), ground.begin(), ground.end());                  // main.rs:335
+
+    primitives::Light area_light{{primitives::Triangle::create({-10.0f, 300.0f, -10.0f}, {10.0f, 300.0f, -10.0f},
+                                                               {0.0f, 300.0f, 0.0f},
+                                                               utils::Color::create(1.0f, 1.0f, 1.0f))}};   // main.rs:337-347
+    int err = RTX_OK;
+    utils::Scene scene{width, height, area_light,
+                       utils::Camera::create({0.0f, 100.0f, 200.0f}, {0.0f, 0.0f, -100000.0f}, {0.0f, 1.0f, 0.0f}, 288.0f),
+                       utils::BoundingVolumeHierarchy::create(std::move(prims), &err)};                       // main.rs:349-358
+    if (err != RTX_OK) { std::fprintf(stderr, "scene: %s\n", rtx_strerror(err)); return 1; }
+
+    std::printf("Rendering...\n");                                            // main.rs:360
+    const auto samples = random_samples(seed);
+    std::vector<uint8_t> rgb;
+    RtxStats st;
+    const auto t0 = std::chrono::steady_clock::now();
+    err = render(scene, samples, rgb, devices, tile_rows, &st);              // main.rs:361
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (err != RTX_OK) { std::fprintf(stderr, "render: %s (hip %d)\n", rtx_strerror(err), rtx_last_hip_error()); return 1; }
+    std::printf("Rendered in %.3f ms (kernel %.3f ms) on %zu device(s)\n", ms, st.kernel_ms, devices.size());
+    std::printf("Throughput %.1fM ray/s (%llu rays: %llu primary + %llu shadow)\n",
+                st.kernel_ms > 0 ? st.rays / st.kernel_ms / 1e3 : 0.0, static_cast<unsigned long long>(st.rays),
+                static_cast<unsigned long long>(st.primary_rays), static_cast<unsigned long long>(st.shadow_rays));
+    std::printf("Writting image to disk\n");                                  // main.rs:312 (sic)
+    err = rtxh_write_png(out.c_str(), width, height, rgb.data());             // main.rs:313-315
+    if (err != RTX_OK) { std::fprintf(stderr, "png: %s\n", rtx_strerror(err)); return 1; }
+    return 0;
+}
