@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -90,13 +91,24 @@ int get_state(RtxScene *scene, int device, DeviceState **out)
     return RTX_OK;
 }
 
+// pad_bytes of zeros follow the data (the node stream carries one sentinel record)
 template <class T>
-int upload_vec(void **dst, const std::vector<T> &v)
+int upload_vec(void **dst, const std::vector<T> &v, size_t pad_bytes = 0)
 {
     const size_t bytes = v.size() * sizeof(T);
-    RTX_HIP(hipMalloc(dst, bytes ? bytes : 16));
+    RTX_HIP(hipMalloc(dst, bytes + pad_bytes ? bytes + pad_bytes : 16));
     if (bytes) RTX_HIP(hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
+    if (pad_bytes) RTX_HIP(hipMemset(static_cast<char *>(*dst) + bytes, 0, pad_bytes));
     return RTX_OK;
+}
+
+uint32_t kernel_variant()
+{
+    static const uint32_t v = [] {
+        const char *e = std::getenv("RTX_VARIANT");
+        return e ? static_cast<uint32_t>(std::atoi(e)) & 7u : rtx::kDefaultVariant;
+    }();
+    return v;
 }
 
 // caller holds st.mu and has the device current
@@ -105,7 +117,7 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     if (st.uploaded) return RTX_OK;
     const rtx::PreparedScene &p = scene->prep;
     int rc;
-    if ((rc = upload_vec(&st.nodes, p.nodes)) != RTX_OK) return rc;
+    if ((rc = upload_vec(&st.nodes, p.nodes, sizeof(rtx::NodeRec))) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.tris, p.tris)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.shade, p.shade)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.samples, p.samples)) != RTX_OK) return rc;
@@ -200,7 +212,8 @@ int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool co
     if (count)
         RTX_HIP(hipMemsetAsync(st.d_counters, 0, rtx::kNumCounters * sizeof(unsigned long long), st.stream));
     RTX_HIP(hipEventRecord(st.ev0, st.stream));
-    RTX_HIP(rtx::launch_trace_shade(device_scene(scene, st), ts, st.d_out, count ? st.d_counters : nullptr, st.stream));
+    RTX_HIP(rtx::launch_trace_shade(device_scene(scene, st), ts, st.d_out, count ? st.d_counters : nullptr, nullptr,
+                                    kernel_variant(), st.stream));
     RTX_HIP(hipEventRecord(st.ev1, st.stream));
     return RTX_OK;
 }
@@ -416,8 +429,40 @@ int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, ui
     if ((rc = ensure_uploaded(scene, *st)) != RTX_OK) return rc;
     const rtx::TileSpec ts{first_tile * tile_rows, tile_rows, tile_stride * tile_rows, rows};
     RTX_HIP(rtx::launch_trace_shade(device_scene(scene, *st), ts, static_cast<uint8_t *>(d_out_rgb),
-                                    reinterpret_cast<unsigned long long *>(d_counters),
+                                    reinterpret_cast<unsigned long long *>(d_counters), nullptr, kernel_variant(),
                                     static_cast<hipStream_t>(stream)));
+    return RTX_OK;
+}
+
+int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t nrows, uint64_t *out,
+                           size_t out_tiles, uint32_t *tiles_x, uint32_t *tiles_y)
+{
+    if (!scene || !tiles_x || !tiles_y) return RTX_ERR_BAD_ARG;
+    const uint32_t H = scene->prep.height;
+    if (row0 > H || nrows > H - row0 || nrows == 0) return RTX_ERR_BAD_ARG;
+    DeviceState *st;
+    int rc = get_state(scene, device, &st);
+    if (rc != RTX_OK) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    DeviceGuard g(device);
+    RTX_HIP(g.status());
+    if ((rc = ensure_uploaded(scene, *st)) != RTX_OK) return rc;
+    const rtx::DeviceScene S = device_scene(scene, *st);
+    *tiles_x = rtx::trace_tiles_x(S, kernel_variant());
+    *tiles_y = (nrows + 7u) / 8u;
+    const size_t n = static_cast<size_t>(*tiles_x) * *tiles_y;
+    if (!out) return RTX_OK;   // size query
+    if (out_tiles < n) return RTX_ERR_BAD_ARG;
+    if ((rc = ensure_out(*st, static_cast<size_t>(nrows) * scene->prep.width * 3u, false)) != RTX_OK) return rc;
+    unsigned long long *d_prof = nullptr;
+    RTX_HIP(hipMalloc(reinterpret_cast<void **>(&d_prof), n * 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_prof, 0, n * 4 * sizeof(unsigned long long), st->stream);
+    const rtx::TileSpec ts{row0, nrows, nrows, nrows};
+    if (e == hipSuccess) e = rtx::launch_trace_shade(S, ts, st->d_out, nullptr, d_prof, kernel_variant(), st->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_prof, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(st->stream);
+    (void)hipFree(d_prof);
+    RTX_HIP(e);
     return RTX_OK;
 }
 

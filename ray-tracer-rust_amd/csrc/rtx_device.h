@@ -12,7 +12,7 @@ namespace rtx {
 // Everything the kernel reads, resident in HBM for the life of the upload.
 // Passed by value (kernarg segment -> SGPRs).
 struct DeviceScene {
-    const NodeRec  *nodes;         // n_nodes x 32 B, pre-order with skip links
+    const NodeRec  *nodes;         // (n_nodes + 1) x 32 B, pre-order with skip links; last = zeroed sentinel
     const TriRec   *tris;          // n_tris x 64 B, leaf order
     const ShadeRec *shade;         // n_tris x 32 B, caller order
     const float2   *samples;       // n_samples x (s.0, s.1)
@@ -38,7 +38,16 @@ struct TileSpec {
 // counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits
 constexpr int kNumCounters = 8;
 
+// variant bits: 1 = conservative multiply-based box test for inner nodes, 2 = prefetch both successor
+// nodes, 4 = one wavefront per workgroup (else four).  kDefaultVariant is what ships; the others stay
+// selectable (RTX_VARIANT) so that profiles can show what each choice is worth.
+constexpr uint32_t kDefaultVariant = 7u;
+
+// d_wave_prof: NULL or 4 uint64 per 8x8 tile {node_visits, tri_visits, t_start, t_end (100 MHz ticks)},
+// row-major over tiles with trace_tiles_x() tiles per row.
+uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
-                              unsigned long long *d_counters, hipStream_t stream);
+                              unsigned long long *d_counters, unsigned long long *d_wave_prof,
+                              uint32_t variant, hipStream_t stream);
 
 }  // namespace rtx

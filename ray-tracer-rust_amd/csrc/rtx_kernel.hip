@@ -4,8 +4,9 @@
 // (src/main.rs:151-240, src/tracer/**); citations are path:line in that repository.
 //
 // Mapping
-//   one work-item per pixel; a 64-lane wavefront owns an 8x8 pixel tile, a 256-thread
-//   workgroup four such tiles side by side (32x8 pixels).
+//   one work-item per pixel; a 64-lane wavefront owns an 8x8 pixel tile.  A workgroup is one
+//   wavefront (no LDS, no barrier: nothing is shared between tiles), so the dispatcher balances
+//   the very uneven tiles (sky: 1 traversal, ground/mesh: 101) at the finest grain.
 //
 // Closest hit (BVHNode::intersect, bounding_volume_hierarchy.rs:50-143)
 //   The acceleration structure is a pre-order, skip-linked BVH stream (scene_prep.h).  A
@@ -14,9 +15,16 @@
 //   the 64 lanes test their own rays against the same box / triangle.  A subtree is skipped
 //   only when NO lane's box test passes (wave ballot), so control flow never diverges and no
 //   per-lane stack exists.  Lanes apply the reference's leaf rule themselves: a triangle hit
-//   counts only if the ray also passes that triangle's own AABB (bvh.rs:52) and t >= 1.0
-//   (bvh.rs:64-67).  Because the reference never prunes by distance, every node whose box
-//   passes is visited here too; the result is the minimum over the same candidate set.
+//   counts only if the ray also passes that triangle's own AABB with the reference's exact slab
+//   arithmetic (bvh.rs:52) and t >= 1.0 (bvh.rs:64-67).  Because the reference never prunes by
+//   distance, every node whose box passes is visited here too; the result is the minimum over
+//   the same candidate set.
+//
+//   Inner-node culling only has to be CONSERVATIVE (never reject a box the exact test accepts):
+//   slab_fast() replaces the six IEEE divisions by multiplications with 1/d and widens the
+//   interval by 2^-20 relative + 2^-100 absolute, which covers the <= 3*2^-24 relative
+//   difference between fl(a*fl(1/d)) and fl(a/d) (DESIGN.md "Conservative culling").  Rays with
+//   a zero / denormal / non-finite direction component take the exact test instead.
 //
 // Arithmetic
 //   IEEE binary32, one rounding per operation, in the reference's operation order; compiled
@@ -65,9 +73,48 @@ __device__ __forceinline__ bool slab_exact(float lox, float loy, float loz, floa
     return inside || (!miss_xy && !miss_z && ok);
 }
 
+// Conservative superset of slab_exact for rays whose direction components are all finite and of
+// magnitude >= 2^-60 (so 1/d is finite and no product is NaN).  ix,iy,iz = 1/d (IEEE division).
+//   exact   q = fl(fl(p-o)/d)          mine  t = fl(fl(p-o)*fl(1/d)),  |t-q| <= 3*2^-24 |q| (+ underflow)
+// near/far per axis = min/max of the two products (same planes as the sign-of-d selection), entry =
+// max of nears, exit = min of fars; the exact test passes only if every near <= every far and every
+// far > 0, so rejecting only when entry exceeds exit by more than the widening, or exit is clearly
+// negative, never rejects a box the exact test accepts (also covers its origin-inside shortcut:
+// then every near <= 0 <= every far).
+__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                          float ox, float oy, float oz, float ix, float iy, float iz)
+{
+    const float ax = (lox - ox) * ix, bx = (hix - ox) * ix;
+    const float ay = (loy - oy) * iy, by = (hiy - oy) * iy;
+    const float az = (loz - oz) * iz, bz = (hiz - oz) * iz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, 0x1p-100f);
+    return !(t_in - t_out > slack) && !(t_out < -0x1p-100f);   // written so that a NaN can only accept
+}
+
+// a node record through the constant address space (scalar loads); field-wise because a struct copy
+// across address spaces has no implicit constructor
+__device__ __forceinline__ NodeRec load_node(const NodeRec RTX_CONSTANT *p)
+{
+    NodeRec r;
+    r.bmin[0] = p->bmin[0]; r.bmin[1] = p->bmin[1]; r.bmin[2] = p->bmin[2];
+    r.link = p->link;
+    r.bmax[0] = p->bmax[0]; r.bmax[1] = p->bmax[1]; r.bmax[2] = p->bmax[2];
+    r.info = p->info;
+    return r;
+}
+
+__device__ __forceinline__ bool direction_is_regular(float dx, float dy, float dz)
+{
+    // false for zero, denormal, NaN, inf components (every comparison with a NaN is false)
+    return fabsf(dx) >= 0x1p-60f && fabsf(dx) <= 2.0f && fabsf(dy) >= 0x1p-60f && fabsf(dy) <= 2.0f &&
+           fabsf(dz) >= 0x1p-60f && fabsf(dz) <= 2.0f;
+}
+
 // One wave-uniform closest-hit traversal.  `active` lanes carry a ray; the others never vote.
 // best_t / best_idx: minimum accepted distance and the caller-order index of its triangle.
-template <bool COUNT>
+template <bool COUNT, bool FAST, bool PREFETCH>
 __device__ __forceinline__ void closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
@@ -80,58 +127,85 @@ __device__ __forceinline__ void closest_hit(const NodeRec RTX_CONSTANT *__restri
     unsigned long long n_active = 0;
     if (COUNT) n_active = __popcll(__ballot(active));
 
+    // fast culling needs regular directions on every active lane; otherwise the whole wave uses the exact test
+    bool use_fast = false;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+    if (FAST) {
+        use_fast = __ballot(active && !direction_is_regular(dx, dy, dz)) == 0ull;
+        ix = 1.0f / dx;
+        iy = 1.0f / dy;
+        iz = 1.0f / dz;
+    }
+
     uint32_t i = 0;
+    NodeRec cur = load_node(nodes);
     while (i < n_nodes) {
-        const NodeRec RTX_CONSTANT *nd = nodes + i;
-        const float lox = nd->bmin[0], loy = nd->bmin[1], loz = nd->bmin[2];
-        const float hix = nd->bmax[0], hiy = nd->bmax[1], hiz = nd->bmax[2];
-        const uint32_t link = nd->link, info = nd->info;
-        const bool pass = active && slab_exact(lox, loy, loz, hix, hiy, hiz, ox, oy, oz, dx, dy, dz);
-        const bool any = __ballot(pass) != 0ull;
-        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
-        const bool leaf = (info & kLeafFlag) != 0u;
-        if (!leaf) {
-            i = any ? i + 1u : link;
-            continue;
+        const bool leaf = (cur.info & kLeafFlag) != 0u;
+        // both possible successors are requested before the box test so that their latency hides behind it
+        // (the array carries one sentinel record past the end, so i+1 and link are always loadable)
+        const uint32_t i_seq = i + 1u;
+        const uint32_t i_skip = leaf ? i_seq : cur.link;
+        NodeRec nxt_seq, nxt_skip;
+        if (PREFETCH) {
+            nxt_seq = load_node(nodes + i_seq);
+            nxt_skip = load_node(nodes + i_skip);
         }
-        i = i + 1u;
-        if (!any) continue;
-        const uint32_t first = info & ~kLeafFlag;
-        for (uint32_t k = 0; k < link; ++k) {
-            const TriRec RTX_CONSTANT *tr = tris + (first + k);
-            const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
-            const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
-            const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
-            if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
-            // Triangle::intersect — triangle.rs:66-94
-            const float pvx = dy * e2z - dz * e2y;                                   // :69
-            const float pvy = dz * e2x - dx * e2z;
-            const float pvz = dx * e2y - dy * e2x;
-            const float det = e1x * pvx + e1y * pvy + e1z * pvz;                     // :70
-            const bool parallel = det < 0.00001f && det > -0.00001f;                 // :73
-            const float inv = 1.0f / det;                                            // :77
-            const float tvx = ox - v0x, tvy = oy - v0y, tvz = oz - v0z;              // :78
-            const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;               // :79
-            const bool out_u = u < 0.0f || u > 1.0f;                                 // :80
-            const float qvx = tvy * e1z - tvz * e1y;                                 // :84
-            const float qvy = tvz * e1x - tvx * e1z;
-            const float qvz = tvx * e1y - tvy * e1x;
-            const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;                  // :85
-            const bool out_v = v < 0.0f || u + v > 1.0f;                             // :86
-            const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;               // :92
-            const bool some = !parallel && !out_u && !out_v;
-            // leaf rule: x < 1.0 -> None (bvh.rs:64-67)
-            if (active && some && !(t < 1.0f)) {
-                // the leaf's own box gates the triangle test in the reference (bvh.rs:52)
-                if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
-                               ox, oy, oz, dx, dy, dz)) {
-                    const uint32_t idx = tr->idx;
-                    bool take = t < best_t;
-                    if (!take && t == best_t && best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
-                        take = shade[idx].rank > shade[best_idx].rank;
-                    if (take) { best_t = t; best_idx = idx; }
+        bool pass;
+        if (FAST && use_fast)
+            pass = slab_fast(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
+                             ox, oy, oz, ix, iy, iz);
+        else
+            pass = slab_exact(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
+                              ox, oy, oz, dx, dy, dz);
+        const bool any = __ballot(active && pass) != 0ull;
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+
+        if (leaf && any) {
+            const uint32_t first = cur.info & ~kLeafFlag;
+            const uint32_t count = cur.link;
+            for (uint32_t k = 0; k < count; ++k) {
+                const TriRec RTX_CONSTANT *tr = tris + (first + k);
+                const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
+                const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
+                const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
+                if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+                // Triangle::intersect — triangle.rs:66-94
+                const float pvx = dy * e2z - dz * e2y;                                   // :69
+                const float pvy = dz * e2x - dx * e2z;
+                const float pvz = dx * e2y - dy * e2x;
+                const float det = e1x * pvx + e1y * pvy + e1z * pvz;                     // :70
+                const bool parallel = det < 0.00001f && det > -0.00001f;                 // :73
+                const float inv = 1.0f / det;                                            // :77
+                const float tvx = ox - v0x, tvy = oy - v0y, tvz = oz - v0z;              // :78
+                const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;               // :79
+                const bool out_u = u < 0.0f || u > 1.0f;                                 // :80
+                const float qvx = tvy * e1z - tvz * e1y;                                 // :84
+                const float qvy = tvz * e1x - tvx * e1z;
+                const float qvz = tvx * e1y - tvy * e1x;
+                const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;                  // :85
+                const bool out_v = v < 0.0f || u + v > 1.0f;                             // :86
+                const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;               // :92
+                const bool some = !parallel && !out_u && !out_v;
+                // leaf rule: x < 1.0 -> None (bvh.rs:64-67)
+                if (active && some && !(t < 1.0f)) {
+                    // the leaf's own box gates the triangle test in the reference (bvh.rs:52): exact arithmetic
+                    if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
+                                   ox, oy, oz, dx, dy, dz)) {
+                        const uint32_t idx = tr->idx;
+                        bool take = t < best_t;
+                        if (!take && t == best_t && best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
+                            take = shade[idx].rank > shade[best_idx].rank;
+                        if (take) { best_t = t; best_idx = idx; }
+                    }
                 }
             }
+        }
+        const bool descend = any || leaf;   // after a leaf (visited or not) and into a passed inner node: next in pre-order
+        i = descend ? i_seq : i_skip;
+        if (PREFETCH) {
+            cur = descend ? nxt_seq : nxt_skip;
+        } else {
+            cur = load_node(nodes + i);
         }
     }
 }
@@ -148,22 +222,28 @@ __device__ __forceinline__ uint32_t quantise(const float *__restrict__ thr, floa
 
 }  // namespace
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256) trace_shade_kernel(DeviceScene S, TileSpec ts, uint8_t *__restrict__ out,
-                                                           unsigned long long *__restrict__ counters)
+// WAVES = wavefronts per workgroup (1 or 4); each wavefront renders one 8x8 tile.
+template <bool COUNT, bool FAST, bool PREFETCH, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) trace_shade_kernel(DeviceScene S, TileSpec ts, uint8_t *__restrict__ out,
+                                                                  unsigned long long *__restrict__ counters,
+                                                                  unsigned long long *__restrict__ wave_prof)
 {
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
     const float RTX_CONSTANT *lights = (const float RTX_CONSTANT *)S.light_points;
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t px = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+    const uint32_t tile_x = blockIdx.x * WAVES + wave;
     // heavy rows (ground, bottom of the frame) are dispatched first
-    const uint32_t ly = (gridDim.y - 1u - blockIdx.y) * 8u + (lane >> 3);
+    const uint32_t tile_y = gridDim.y - 1u - blockIdx.y;
+    const uint32_t px = tile_x * 8u + (lane & 7u);
+    const uint32_t ly = tile_y * 8u + (lane >> 3);
     const uint32_t tile = ly / ts.tile_rows;
     const uint32_t py = ts.first_row + tile * ts.tile_stride_rows + (ly - tile * ts.tile_rows);
     const bool in_frame = px < S.width && ly < ts.local_rows && py < S.height;
 
+    unsigned long long t_start = 0;
+    if (COUNT) t_start = wall_clock64();
     WaveCounters wc;
     unsigned long long primary_hits = 0;
 
@@ -188,8 +268,8 @@ __global__ void __launch_bounds__(256) trace_shade_kernel(DeviceScene S, TileSpe
 
         float t;
         uint32_t idx;
-        closest_hit<COUNT>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1], S.eye[2],
-                           dx, dy, dz, t, idx, wc);                                   // main.rs:187
+        closest_hit<COUNT, FAST, PREFETCH>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1], S.eye[2],
+                                           dx, dy, dz, t, idx, wc);                   // main.rs:187
         const bool hit = in_frame && idx != kNone;
         const unsigned long long hit_mask = __ballot(hit);
         if (hit_mask == 0ull) continue;                                               // main.rs:235
@@ -211,7 +291,8 @@ __global__ void __launch_bounds__(256) trace_shade_kernel(DeviceScene S, TileSpe
             const float sx = vx / dist_light, sy = vy / dist_light, sz = vz / dist_light;   // main.rs:201
             float st;
             uint32_t sidx;
-            closest_hit<COUNT>(nodes, tris, S.shade, S.n_nodes, hit, hx, hy, hz, sx, sy, sz, st, sidx, wc);  // main.rs:204
+            closest_hit<COUNT, FAST, PREFETCH>(nodes, tris, S.shade, S.n_nodes, hit, hx, hy, hz, sx, sy, sz,
+                                               st, sidx, wc);                         // main.rs:204
             const float lnd = fabsf(nx * sx + ny * sy + nz * sz);                     // main.rs:207
             bool lit = true;                                                          // main.rs:229-231
             if (sidx != kNone) {                                                      // main.rs:219-227
@@ -233,25 +314,72 @@ __global__ void __launch_bounds__(256) trace_shade_kernel(DeviceScene S, TileSpe
         p[2] = (uint8_t)quantise(S.gamma_thr, acc_b);
     }
 
-    if (COUNT && lane == 0 && counters) {
-        atomicAdd(&counters[0], primary_hits);
-        atomicAdd(&counters[1], wc.box_tests);
-        atomicAdd(&counters[2], wc.tri_tests);
-        atomicAdd(&counters[3], wc.node_visits);
-        atomicAdd(&counters[4], wc.tri_visits);
+    if (COUNT && lane == 0) {
+        if (counters) {
+            atomicAdd(&counters[0], primary_hits);
+            atomicAdd(&counters[1], wc.box_tests);
+            atomicAdd(&counters[2], wc.tri_tests);
+            atomicAdd(&counters[3], wc.node_visits);
+            atomicAdd(&counters[4], wc.tri_visits);
+        }
+        if (wave_prof) {   // diagnostics: per-tile work and residency (rtx_debug_wave_profile)
+            const uint32_t tiles_x = gridDim.x * WAVES;
+            unsigned long long *p = wave_prof + 4ull * ((unsigned long long)tile_y * tiles_x + tile_x);
+            p[0] = wc.node_visits;
+            p[1] = wc.tri_visits;
+            p[2] = t_start;
+            p[3] = wall_clock64();
+        }
     }
 }
 
+namespace {
+
+template <bool COUNT, bool FAST, bool PREFETCH, int WAVES>
+void launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, unsigned long long *d_counters,
+                    unsigned long long *d_wave_prof, hipStream_t stream)
+{
+    const uint32_t tiles_x = (S.width + 7u) / 8u;
+    const dim3 block(64 * WAVES);
+    const dim3 grid((tiles_x + WAVES - 1) / WAVES, (ts.local_rows + 7u) / 8u);
+    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, PREFETCH, WAVES>), grid, block, 0, stream, S, ts, d_out,
+                       d_counters, d_wave_prof);
+}
+
+template <bool COUNT>
+void launch_select(uint32_t variant, const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
+                   unsigned long long *d_counters, unsigned long long *d_wave_prof, hipStream_t stream)
+{
+    switch (variant & 7u) {
+    case 0: launch_variant<COUNT, false, false, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 1: launch_variant<COUNT, true, false, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 2: launch_variant<COUNT, false, true, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 3: launch_variant<COUNT, true, true, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 4: launch_variant<COUNT, false, false, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 5: launch_variant<COUNT, true, false, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 6: launch_variant<COUNT, false, true, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    default: launch_variant<COUNT, true, true, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    }
+}
+
+}  // namespace
+
+uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant)
+{
+    const uint32_t tiles_x = (S.width + 7u) / 8u;
+    const uint32_t waves = (variant & 4u) ? 1u : 4u;
+    return (tiles_x + waves - 1u) / waves * waves;
+}
+
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
-                              unsigned long long *d_counters, hipStream_t stream)
+                              unsigned long long *d_counters, unsigned long long *d_wave_prof,
+                              uint32_t variant, hipStream_t stream)
 {
     if (ts.local_rows == 0) return hipSuccess;
-    const dim3 block(256);
-    const dim3 grid((S.width + 31u) / 32u, (ts.local_rows + 7u) / 8u);
-    if (d_counters)
-        hipLaunchKernelGGL(trace_shade_kernel<true>, grid, block, 0, stream, S, ts, d_out, d_counters);
+    if (d_counters || d_wave_prof)
+        launch_select<true>(variant, S, ts, d_out, d_counters, d_wave_prof, stream);
     else
-        hipLaunchKernelGGL(trace_shade_kernel<false>, grid, block, 0, stream, S, ts, d_out, d_counters);
+        launch_select<false>(variant, S, ts, d_out, d_counters, d_wave_prof, stream);
     return hipGetLastError();
 }
 

@@ -91,6 +91,7 @@ _SIGS = {
                                           C.c_size_t, C.c_void_p, C.c_void_p]),
     "rtx_tiles_rows": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rtx_tiles_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rtx_debug_wave_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u32p, u32p]),
     "rtx_strerror": (C.c_char_p, [C.c_int]),
     "rtx_last_hip_error": (C.c_int, []),
     "rtx_scene_light_points": (C.c_int, [C.c_void_p, f32p]),
@@ -300,6 +301,18 @@ class Scene:
         _check(_lib.rtx_render_frame(self._h, devs, len(devices), tile_rows, out.ctypes.data,
                                      C.byref(st) if stats else None), "rtx_render_frame")
         return (out, st.asdict()) if stats else out
+
+    def wave_profile(self, row0=0, nrows=None, device=0):
+        """Diagnostics: [tiles_y, tiles_x, 4] uint64 {node fetches, triangle fetches, start, end (100 MHz ticks)}."""
+        if nrows is None:
+            nrows = self.height - row0
+        tx, ty = C.c_uint32(), C.c_uint32()
+        _check(_lib.rtx_debug_wave_profile(self._h, device, row0, nrows, None, 0, C.byref(tx), C.byref(ty)),
+               "rtx_debug_wave_profile")
+        out = np.zeros((ty.value, tx.value, 4), np.uint64)
+        _check(_lib.rtx_debug_wave_profile(self._h, device, row0, nrows, out.ctypes.data_as(u64p), tx.value * ty.value,
+                                           C.byref(tx), C.byref(ty)), "rtx_debug_wave_profile")
+        return out
 
     def tiles_rows(self, first_tile, tile_stride, tile_rows):
         return _lib.rtx_tiles_rows(self._h, first_tile, tile_stride, tile_rows)
