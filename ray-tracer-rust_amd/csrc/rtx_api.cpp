@@ -463,6 +463,7 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     if (e == hipSuccess) e = hipStreamSynchronize(st->stream);
     (void)hipFree(d_prof);
     RTX_HIP(e);
+    for (size_t t = 0; t < n; ++t) out[4 * t + 2] = ~out[4 * t + 2];   // the kernel keeps the earliest start as max(~t)
     return RTX_OK;
 }
 

@@ -38,13 +38,16 @@ struct TileSpec {
 // counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits
 constexpr int kNumCounters = 8;
 
-// variant bits: 1 = conservative multiply-based box test for inner nodes, 2 = prefetch both successor
-// nodes, 4 = one wavefront per workgroup (else four).  kDefaultVariant is what ships; the others stay
-// selectable (RTX_VARIANT) so that profiles can show what each choice is worth.
-constexpr uint32_t kDefaultVariant = 7u;
+// Light samples per LDS batch (results of one batch: 64 pixels x batch floats).
+constexpr uint32_t kMaxLightBatch = 128u;
 
-// d_wave_prof: NULL or 4 uint64 per 8x8 tile {node_visits, tri_visits, t_start, t_end (100 MHz ticks)},
-// row-major over tiles with trace_tiles_x() tiles per row.
+// Kernel variants, kept selectable (RTX_VARIANT) so that profiles can show what each choice is worth:
+// bit 0 = conservative multiply-based box test for inner nodes (else the exact division-based one);
+// bits 1-2 = wavefronts per workgroup: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1.
+constexpr uint32_t kDefaultVariant = 1u;
+
+// d_wave_prof: NULL or 4 uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end (100 MHz ticks)},
+// zero-initialised by the caller, row-major over tiles with trace_tiles_x() tiles per row.
 uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
                               unsigned long long *d_counters, unsigned long long *d_wave_prof,

@@ -3,10 +3,21 @@
 // Replaces render_pixel() + everything below it in the reference
 // (src/main.rs:151-240, src/tracer/**); citations are path:line in that repository.
 //
-// Mapping
-//   one work-item per pixel; a 64-lane wavefront owns an 8x8 pixel tile.  A workgroup is one
-//   wavefront (no LDS, no barrier: nothing is shared between tiles), so the dispatcher balances
-//   the very uneven tiles (sky: 1 traversal, ground/mesh: 101) at the finest grain.
+// Work decomposition (one launch, one workgroup per 8x8 pixel tile, NW wavefronts per workgroup)
+//   phase 1  one work-item per pixel: wave 0 generates the 64 primary rays of the tile and finds
+//            their closest hits; hit pixels are compacted and their hit point + normal go to LDS.
+//   phase 2  one work-item per shadow ray: the (hit pixel, light sample) pairs of the tile are
+//            numbered pixel-major and dealt to the NW waves in chunks of 64 consecutive rays, so a
+//            wavefront's rays leave from at most two surface points towards the small area light —
+//            a thin shaft, which is what makes the wave-uniform traversal below cheap.  Each ray
+//            stores |n.l| (lit) or a marker (occluded) in LDS.
+//   phase 3  one work-item per pixel again: wave 0 adds the samples of each pixel in sample order,
+//            exactly the reference's sequential f32 accumulation (main.rs:209-216), quantises and
+//            stores RGB8.
+//   The reference runs the 100 shadow traversals of a pixel back to back; with one lane per pixel
+//   that serial chain (x the lanes' union of BVH nodes on mesh-surface tiles) left one tile running
+//   for 15 ms after 95 % of the frame was done (profiles/r01/b_*).  Phase 2 cuts the chain by NW
+//   and shrinks each traversal's node set.
 //
 // Closest hit (BVHNode::intersect, bounding_volume_hierarchy.rs:50-143)
 //   The acceleration structure is a pre-order, skip-linked BVH stream (scene_prep.h).  A
@@ -45,6 +56,7 @@ namespace rtx {
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr float kOccluded = -1.0f;   // |n.l| is never negative; marks an occluded sample in LDS
 
 struct WaveCounters {
     unsigned long long box_tests = 0, tri_tests = 0, node_visits = 0, tri_visits = 0;
@@ -114,7 +126,7 @@ __device__ __forceinline__ bool direction_is_regular(float dx, float dy, float d
 
 // One wave-uniform closest-hit traversal.  `active` lanes carry a ray; the others never vote.
 // best_t / best_idx: minimum accepted distance and the caller-order index of its triangle.
-template <bool COUNT, bool FAST, bool PREFETCH>
+template <bool COUNT, bool FAST>
 __device__ __forceinline__ void closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
@@ -138,18 +150,9 @@ __device__ __forceinline__ void closest_hit(const NodeRec RTX_CONSTANT *__restri
     }
 
     uint32_t i = 0;
-    NodeRec cur = load_node(nodes);
     while (i < n_nodes) {
+        const NodeRec cur = load_node(nodes + i);
         const bool leaf = (cur.info & kLeafFlag) != 0u;
-        // both possible successors are requested before the box test so that their latency hides behind it
-        // (the array carries one sentinel record past the end, so i+1 and link are always loadable)
-        const uint32_t i_seq = i + 1u;
-        const uint32_t i_skip = leaf ? i_seq : cur.link;
-        NodeRec nxt_seq, nxt_skip;
-        if (PREFETCH) {
-            nxt_seq = load_node(nodes + i_seq);
-            nxt_skip = load_node(nodes + i_skip);
-        }
         bool pass;
         if (FAST && use_fast)
             pass = slab_fast(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
@@ -200,13 +203,8 @@ __device__ __forceinline__ void closest_hit(const NodeRec RTX_CONSTANT *__restri
                 }
             }
         }
-        const bool descend = any || leaf;   // after a leaf (visited or not) and into a passed inner node: next in pre-order
-        i = descend ? i_seq : i_skip;
-        if (PREFETCH) {
-            cur = descend ? nxt_seq : nxt_skip;
-        } else {
-            cur = load_node(nodes + i);
-        }
+        // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
+        i = (any || leaf) ? i + 1u : cur.link;
     }
 }
 
@@ -222,20 +220,31 @@ __device__ __forceinline__ uint32_t quantise(const float *__restrict__ thr, floa
 
 }  // namespace
 
-// WAVES = wavefronts per workgroup (1 or 4); each wavefront renders one 8x8 tile.
-template <bool COUNT, bool FAST, bool PREFETCH, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) trace_shade_kernel(DeviceScene S, TileSpec ts, uint8_t *__restrict__ out,
-                                                                  unsigned long long *__restrict__ counters,
-                                                                  unsigned long long *__restrict__ wave_prof)
+// LDS image of a workgroup (floats): light points of the current batch [3*batch], hit records
+// [64][8] = {p_hit.xyz, normal.xyz, -, -}, sample results [64][res_stride], hit count [1].
+__host__ __device__ inline uint32_t lds_res_stride(uint32_t batch) { return batch | 1u; }   // odd: conflict-free column reads
+__host__ __device__ inline uint32_t lds_floats(uint32_t batch) { return 3u * batch + 64u * 8u + 64u * lds_res_stride(batch) + 4u; }
+
+template <bool COUNT, bool FAST, int NW>
+__global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch,
+                                                               uint8_t *__restrict__ out,
+                                                               unsigned long long *__restrict__ counters,
+                                                               unsigned long long *__restrict__ wave_prof)
 {
+    extern __shared__ __align__(16) float lds[];
+    float *const l_light = lds;
+    float *const l_hit = l_light + 3u * batch;
+    float *const l_res = l_hit + 64u * 8u;
+    const uint32_t res_stride = lds_res_stride(batch);
+    uint32_t *const l_nhit = reinterpret_cast<uint32_t *>(l_res + 64u * res_stride);
+
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    const float RTX_CONSTANT *lights = (const float RTX_CONSTANT *)S.light_points;
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t tile_x = blockIdx.x * WAVES + wave;
-    // heavy rows (ground, bottom of the frame) are dispatched first
-    const uint32_t tile_y = gridDim.y - 1u - blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile_x = blockIdx.x;
+    const uint32_t tile_y = gridDim.y - 1u - blockIdx.y;   // heavy rows (ground, bottom of the frame) first
     const uint32_t px = tile_x * 8u + (lane & 7u);
     const uint32_t ly = tile_y * 8u + (lane >> 3);
     const uint32_t tile = ly / ts.tile_rows;
@@ -247,67 +256,104 @@ __global__ void __launch_bounds__(64 * WAVES) trace_shade_kernel(DeviceScene S, 
     WaveCounters wc;
     unsigned long long primary_hits = 0;
 
-    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;                                  // main.rs:182
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;                                  // main.rs:182 (wave 0 only)
     const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
-        // create_rays — main.rs:151-178
-        float s0 = 0.0f, s1 = 0.0f;
-        if (in_frame) {
-            const uint32_t k = (px * S.width + py + r) % S.n_samples;                // :162,165 (u32)
-            const float2 s = S.samples[k];
-            s0 = s.x;
-            s1 = s.y;
-        }
-        const float a = (float)px - (float)S.width / 2.0f + s0;                      // :161-162
-        const float b = (float)py - (float)S.height / 2.0f + s1;                     // :164-165
-        const float rx = (a * S.cu[0] + b * S.cv[0]) - S.distance * S.cw[0];         // :160-167
-        const float ry = (a * S.cu[1] + b * S.cv[1]) - S.distance * S.cw[1];
-        const float rz = (a * S.cu[2] + b * S.cv[2]) - S.distance * S.cw[2];
-        const float rn = sqrtf(rx * rx + ry * ry + rz * rz);                         // Ray::new, ray.rs:15
-        const float dx = rx / rn, dy = ry / rn, dz = rz / rn;
-
-        float t;
-        uint32_t idx;
-        closest_hit<COUNT, FAST, PREFETCH>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1], S.eye[2],
-                                           dx, dy, dz, t, idx, wc);                   // main.rs:187
-        const bool hit = in_frame && idx != kNone;
-        const unsigned long long hit_mask = __ballot(hit);
-        if (hit_mask == 0ull) continue;                                               // main.rs:235
-        if (COUNT) primary_hits += __popcll(hit_mask);
-
-        float hx = 0.0f, hy = 0.0f, hz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-        if (hit) {
-            hx = S.eye[0] + t * dx;                                                   // bvh.rs:69
-            hy = S.eye[1] + t * dy;
-            hz = S.eye[2] + t * dz;
-            const ShadeRec sh = S.shade[idx];
-            nx = sh.normal[0]; ny = sh.normal[1]; nz = sh.normal[2];                  // main.rs:206
-            cr = sh.rgb[0]; cg = sh.rgb[1]; cb = sh.rgb[2];                           // main.rs:191
-        }
-        for (uint32_t i = 0; i < S.nb_light; ++i) {                                   // main.rs:193
-            const float RTX_CONSTANT *lp = lights + 3u * (r * S.nb_light + i);        // main.rs:194-196 (hoisted)
-            const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;            // p - orig
-            const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);              // main.rs:202
-            const float sx = vx / dist_light, sy = vy / dist_light, sz = vz / dist_light;   // main.rs:201
-            float st;
-            uint32_t sidx;
-            closest_hit<COUNT, FAST, PREFETCH>(nodes, tris, S.shade, S.n_nodes, hit, hx, hy, hz, sx, sy, sz,
-                                               st, sidx, wc);                         // main.rs:204
-            const float lnd = fabsf(nx * sx + ny * sy + nz * sz);                     // main.rs:207
-            bool lit = true;                                                          // main.rs:229-231
-            if (sidx != kNone) {                                                      // main.rs:219-227
-                const float qx = hx - (hx + st * sx), qy = hy - (hy + st * sy), qz = hz - (hz + st * sz);
-                lit = sqrtf(qx * qx + qy * qy + qz * qz) > dist_light;
+        // ---------------- phase 1: primary rays, one work-item per pixel (wave 0) ----------------
+        bool hit = false;
+        uint32_t slot = 0;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        if (wave == 0) {
+            // create_rays — main.rs:151-178
+            float s0 = 0.0f, s1 = 0.0f;
+            if (in_frame) {
+                const uint32_t k = (px * S.width + py + r) % S.n_samples;            // :162,165 (u32)
+                const float2 s = S.samples[k];
+                s0 = s.x;
+                s1 = s.y;
             }
-            if (hit && lit) {                                                         // main.rs:209-216
-                acc_r = acc_r + ((cr * lnd) / denom);
-                acc_g = acc_g + ((cg * lnd) / denom);
-                acc_b = acc_b + ((cb * lnd) / denom);
+            const float a = (float)px - (float)S.width / 2.0f + s0;                  // :161-162
+            const float b = (float)py - (float)S.height / 2.0f + s1;                 // :164-165
+            const float rx = (a * S.cu[0] + b * S.cv[0]) - S.distance * S.cw[0];     // :160-167
+            const float ry = (a * S.cu[1] + b * S.cv[1]) - S.distance * S.cw[1];
+            const float rz = (a * S.cu[2] + b * S.cv[2]) - S.distance * S.cw[2];
+            const float rn = sqrtf(rx * rx + ry * ry + rz * rz);                     // Ray::new, ray.rs:15
+            const float dx = rx / rn, dy = ry / rn, dz = rz / rn;
+            float t;
+            uint32_t idx;
+            closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1], S.eye[2],
+                                     dx, dy, dz, t, idx, wc);                         // main.rs:187
+            hit = in_frame && idx != kNone;
+            const unsigned long long hit_mask = __ballot(hit);
+            slot = __popcll(hit_mask & ((1ull << lane) - 1ull));                      // compacted index of this pixel
+            if (COUNT) primary_hits += __popcll(hit_mask);
+            if (hit) {
+                const ShadeRec sh = S.shade[idx];
+                float *h = l_hit + 8u * slot;
+                h[0] = S.eye[0] + t * dx;                                             // p_hit, bvh.rs:69
+                h[1] = S.eye[1] + t * dy;
+                h[2] = S.eye[2] + t * dz;
+                h[3] = sh.normal[0]; h[4] = sh.normal[1]; h[5] = sh.normal[2];        // main.rs:206
+                cr = sh.rgb[0]; cg = sh.rgb[1]; cb = sh.rgb[2];                       // main.rs:191
+            }
+            if (lane == 0) *l_nhit = (uint32_t)__popcll(hit_mask);
+        }
+        __syncthreads();
+        const uint32_t n_hit = __builtin_amdgcn_readfirstlane(*l_nhit);
+        if (n_hit != 0u) {                                                            // else main.rs:235
+            for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                     // main.rs:193, in batches that fit LDS
+                const uint32_t bc = (S.nb_light - b0 < batch) ? S.nb_light - b0 : batch;
+                // light points of this batch: get_sample(T[(r*NB_RAY+i) % n]), main.rs:194-196 (hoisted to the host)
+                for (uint32_t k = threadIdx.x; k < 3u * bc; k += 64u * NW)
+                    l_light[k] = S.light_points[3u * (r * S.nb_light + b0) + k];
+                __syncthreads();
+
+                // ------------- phase 2: shadow rays, one work-item per (hit pixel, sample) -------------
+                const uint32_t total = n_hit * bc;
+                for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
+                    const uint32_t ray = c0 + lane;
+                    const bool valid = ray < total;
+                    const uint32_t hp = valid ? ray / bc : 0u;
+                    const uint32_t si = valid ? ray - hp * bc : 0u;
+                    const float *h = l_hit + 8u * hp;
+                    const float hx = h[0], hy = h[1], hz = h[2];
+                    const float vx = l_light[3u * si] - hx, vy = l_light[3u * si + 1u] - hy,
+                                vz = l_light[3u * si + 2u] - hz;                       // p - orig
+                    const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);      // main.rs:202
+                    const float sx = vx / dist_light, sy = vy / dist_light, sz = vz / dist_light;   // main.rs:201
+                    float st;
+                    uint32_t sidx;
+                    closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, valid, hx, hy, hz, sx, sy, sz,
+                                             st, sidx, wc);                           // main.rs:204
+                    const float lnd = fabsf(h[3] * sx + h[4] * sy + h[5] * sz);       // main.rs:207
+                    bool lit = true;                                                  // main.rs:229-231
+                    if (sidx != kNone) {                                              // main.rs:219-227
+                        const float qx = hx - (hx + st * sx), qy = hy - (hy + st * sy), qz = hz - (hz + st * sz);
+                        lit = sqrtf(qx * qx + qy * qy + qz * qz) > dist_light;
+                    }
+                    if (valid) l_res[hp * res_stride + si] = lit ? lnd : kOccluded;
+                }
+                __syncthreads();
+
+                // ------------- phase 3: ordered accumulation, one work-item per pixel (wave 0) -------------
+                if (wave == 0 && hit) {
+                    const float *res = l_res + slot * res_stride;
+                    for (uint32_t i = 0; i < bc; ++i) {                               // i ascending, main.rs:209-216
+                        const float lnd = res[i];
+                        if (!(lnd < 0.0f)) {
+                            acc_r = acc_r + ((cr * lnd) / denom);
+                            acc_g = acc_g + ((cg * lnd) / denom);
+                            acc_b = acc_b + ((cb * lnd) / denom);
+                        }
+                    }
+                }
+                __syncthreads();   // results and light points are overwritten by the next batch / ray
             }
         }
+        __syncthreads();           // l_nhit and hit records are rewritten by the next primary ray
     }
 
-    if (in_frame) {                                                                   // put_pixel, main.rs:293-294
+    if (wave == 0 && in_frame) {                                                      // put_pixel, main.rs:293-294
         uint8_t *p = out + ((size_t)ly * S.width + px) * 3u;
         p[0] = (uint8_t)quantise(S.gamma_thr, acc_r);
         p[1] = (uint8_t)quantise(S.gamma_thr, acc_g);
@@ -316,71 +362,64 @@ __global__ void __launch_bounds__(64 * WAVES) trace_shade_kernel(DeviceScene S, 
 
     if (COUNT && lane == 0) {
         if (counters) {
-            atomicAdd(&counters[0], primary_hits);
+            if (wave == 0) atomicAdd(&counters[0], primary_hits);
             atomicAdd(&counters[1], wc.box_tests);
             atomicAdd(&counters[2], wc.tri_tests);
             atomicAdd(&counters[3], wc.node_visits);
             atomicAdd(&counters[4], wc.tri_visits);
         }
-        if (wave_prof) {   // diagnostics: per-tile work and residency (rtx_debug_wave_profile)
-            const uint32_t tiles_x = gridDim.x * WAVES;
-            unsigned long long *p = wave_prof + 4ull * ((unsigned long long)tile_y * tiles_x + tile_x);
-            p[0] = wc.node_visits;
-            p[1] = wc.tri_visits;
-            p[2] = t_start;
-            p[3] = wall_clock64();
+        if (wave_prof) {   // diagnostics: per-tile work and residency (rtx_debug_wave_profile); buffer pre-set by the host
+            unsigned long long *p = wave_prof + 4ull * ((unsigned long long)tile_y * gridDim.x + tile_x);
+            atomicAdd(&p[0], wc.node_visits);
+            atomicAdd(&p[1], wc.tri_visits);
+            atomicMax(&p[2], ~t_start);   // stored inverted so that a zeroed buffer works as the identity
+            atomicMax(&p[3], (unsigned long long)wall_clock64());
         }
     }
 }
 
 namespace {
 
-template <bool COUNT, bool FAST, bool PREFETCH, int WAVES>
-void launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, unsigned long long *d_counters,
-                    unsigned long long *d_wave_prof, hipStream_t stream)
+template <bool COUNT, bool FAST, int NW>
+hipError_t launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, unsigned long long *d_counters,
+                          unsigned long long *d_wave_prof, hipStream_t stream)
 {
-    const uint32_t tiles_x = (S.width + 7u) / 8u;
-    const dim3 block(64 * WAVES);
-    const dim3 grid((tiles_x + WAVES - 1) / WAVES, (ts.local_rows + 7u) / 8u);
-    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, PREFETCH, WAVES>), grid, block, 0, stream, S, ts, d_out,
+    const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
+    const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
+    const dim3 block(64 * NW);
+    const dim3 grid((S.width + 7u) / 8u, (ts.local_rows + 7u) / 8u);
+    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, NW>), grid, block, lds_bytes, stream, S, ts, batch, d_out,
                        d_counters, d_wave_prof);
+    return hipGetLastError();
 }
 
 template <bool COUNT>
-void launch_select(uint32_t variant, const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
-                   unsigned long long *d_counters, unsigned long long *d_wave_prof, hipStream_t stream)
+hipError_t launch_select(uint32_t variant, const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
+                         unsigned long long *d_counters, unsigned long long *d_wave_prof, hipStream_t stream)
 {
     switch (variant & 7u) {
-    case 0: launch_variant<COUNT, false, false, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    case 1: launch_variant<COUNT, true, false, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    case 2: launch_variant<COUNT, false, true, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    case 3: launch_variant<COUNT, true, true, 4>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    case 4: launch_variant<COUNT, false, false, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    case 5: launch_variant<COUNT, true, false, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    case 6: launch_variant<COUNT, false, true, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
-    default: launch_variant<COUNT, true, true, 1>(S, ts, d_out, d_counters, d_wave_prof, stream); break;
+    case 0: return launch_variant<COUNT, false, 4>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    case 1: return launch_variant<COUNT, true, 4>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    case 2: return launch_variant<COUNT, false, 8>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    case 3: return launch_variant<COUNT, true, 8>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    case 4: return launch_variant<COUNT, false, 2>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    case 5: return launch_variant<COUNT, true, 2>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    case 6: return launch_variant<COUNT, false, 1>(S, ts, d_out, d_counters, d_wave_prof, stream);
+    default: return launch_variant<COUNT, true, 1>(S, ts, d_out, d_counters, d_wave_prof, stream);
     }
 }
 
 }  // namespace
 
-uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant)
-{
-    const uint32_t tiles_x = (S.width + 7u) / 8u;
-    const uint32_t waves = (variant & 4u) ? 1u : 4u;
-    return (tiles_x + waves - 1u) / waves * waves;
-}
+uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant) { return (S.width + 7u) / 8u; }
 
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
                               unsigned long long *d_counters, unsigned long long *d_wave_prof,
                               uint32_t variant, hipStream_t stream)
 {
     if (ts.local_rows == 0) return hipSuccess;
-    if (d_counters || d_wave_prof)
-        launch_select<true>(variant, S, ts, d_out, d_counters, d_wave_prof, stream);
-    else
-        launch_select<false>(variant, S, ts, d_out, d_counters, d_wave_prof, stream);
-    return hipGetLastError();
+    if (d_counters || d_wave_prof) return launch_select<true>(variant, S, ts, d_out, d_counters, d_wave_prof, stream);
+    return launch_select<false>(variant, S, ts, d_out, d_counters, d_wave_prof, stream);
 }
 
 }  // namespace rtx

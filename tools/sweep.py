@@ -63,9 +63,12 @@ def main():
         for v in range(8):
             run_child({"RTX_VARIANT": str(v)})
     elif mode == "leaf":
-        for leaf in (1, 2, 4, 6, 8, 12, 16):
-            for cost in ("0.5", "1.0", "2.0"):
-                run_child({"RTX_LEAF_MAX": str(leaf), "RTX_SAH_BOX_COST": cost})
+        variant = sys.argv[2] if len(sys.argv) > 2 else "3"
+        for leaf in (1, 2, 3, 4, 8):
+            for cost in ("0.125", "0.25", "0.5", "1.0"):
+                if leaf == 1 and cost != "0.25":
+                    continue     # the SAH termination cannot matter when every leaf holds one triangle
+                run_child({"RTX_LEAF_MAX": str(leaf), "RTX_SAH_BOX_COST": cost, "RTX_VARIANT": variant})
     elif mode == "waveprof":
         import numpy as np
         rtx = importlib.import_module("ray-tracer-rust_amd")
