@@ -44,7 +44,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak (counts an FMA as 2 flop)
 FLOP_PER_TRI_TEST = 46         # full Möller–Trumbore path incl. the division
-FLOP_PER_BOX_TEST = 30         # 6 sub + 6 div + 18 compare/select
+FLOP_PER_BOX_TEST = 28         # conservative box test: 6 sub, 6 mul, 6 min/max, max3+min3 (4), add, fma (2), sub, 2 cmp
 BYTES_PER_TRI_REC = 36         # v0,e1,e2 consumed per test
 BYTES_PER_BOX_REC = 24         # bmin,bmax
 BYTES_PER_PIXEL_IO = 11        # 8 B of the sample table + 3 B framebuffer
@@ -94,6 +94,23 @@ def cpu_baseline(wl, samples_np, seconds, threads):
     }
 
 
+def reduce_counters(counters, world):
+    """Sum the per-rank kernel counters (each rank counted only its own row tiles)."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+    return counters.cpu().tolist()
+
+
+def reduce_times(elapsed_s, kernel_s, world, device):
+    """MAX over ranks of the timed region and of the per-launch kernel time."""
+    tt = torch.tensor([elapsed_s, kernel_s], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return tt.cpu().tolist()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -131,16 +148,15 @@ def main():
                                   stream.cuda_stream, counters.data_ptr() if count else None)
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
 
     # one counted launch (outside the timed region) gives the frame's ray / test counts
     step(count=True)
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
-    c = counters.cpu().tolist()
+    c = reduce_counters(counters, world)
     primary_hits, box_tests, tri_tests, node_visits, tri_visits = c[0], c[1], c[2], c[3], c[4]
     primary_rays = W * H * rtx.NB_RAY
     r_total = primary_rays + rtx.NB_LIGHT_SAMPLE * primary_hits
@@ -157,10 +173,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)   # this rank's launches
-    tt = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, kernel_s = tt.cpu().tolist()
+    elapsed, kernel_s = reduce_times(elapsed, kernel_ms / 1e3, world, dev)
     ms_per_step = elapsed / args.steps * 1e3
 
     if args.save_png and world == 1:

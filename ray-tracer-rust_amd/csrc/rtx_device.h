@@ -44,7 +44,7 @@ constexpr uint32_t kMaxLightBatch = 128u;
 // Kernel variants, kept selectable (RTX_VARIANT) so that profiles can show what each choice is worth:
 // bit 0 = conservative multiply-based box test for inner nodes (else the exact division-based one);
 // bits 1-2 = wavefronts per workgroup: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1.
-constexpr uint32_t kDefaultVariant = 1u;
+constexpr uint32_t kDefaultVariant = 3u;
 
 // d_wave_prof: NULL or 4 uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end (100 MHz ticks)},
 // zero-initialised by the caller, row-major over tiles with trace_tiles_x() tiles per row.

@@ -1,0 +1,115 @@
+"""The N > 1 path on CPU: two gloo ranks (127.0.0.1) run the sharding plumbing bench.py uses with one
+rank per GPU — tile ownership, packed-tile sizes from the C ABI, gather + scatter into a frame, and
+the SUM / MAX reductions — with the golden image standing in for the device output (no GPU here, and
+the product has no CPU renderer).  The GPU side of the same partition is covered on one device by
+tests/test_gpu_parity.py::test_rows_tiles_and_frames_are_identical."""
+import importlib
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NAME = "ragged_bigbunny_203x117_seed"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, tile_rows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rtx = importlib.import_module("ray-tracer-rust_amd")
+        import bench
+        gold = np.asarray(Image.open(os.path.join(GOLD, NAME + ".png")).convert("RGB"))
+        H, W, _ = gold.shape
+        scene = rtx.default_scene([os.path.join(ROOT, "models", "big_bunny.obj")], W, H, rtx.gen_samples(n_pairs=4096),
+                                  tie_rank=None)
+        rows = scene.tiles_rows(rank, world, tile_rows)
+        nbytes = scene.tiles_bytes(rank, world, tile_rows)
+        assert nbytes == rows * W * 3
+        # what this rank's launch would have produced: its tiles, packed
+        mine = [gold[t * tile_rows:(t + 1) * tile_rows] for t in range(rank, -(-H // tile_rows), world)]
+        packed = np.concatenate(mine) if mine else np.zeros((0, W, 3), np.uint8)
+        assert len(packed) == rows
+        # every rank reports its row count; together they cover the frame exactly once
+        counts = torch.zeros(world, dtype=torch.int64)
+        counts[rank] = rows
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        assert int(counts.sum()) == H
+        # gather the packed tiles on rank 0 (padded to the largest share) and rebuild the frame
+        cap = int(counts.max()) * W * 3
+        buf = torch.zeros(cap, dtype=torch.uint8)
+        buf[:nbytes] = torch.from_numpy(packed.reshape(-1).copy())
+        parts = [torch.zeros(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, parts, dst=0)
+        # the reductions bench.py performs
+        c = bench.reduce_counters(torch.tensor([10 + rank, 1, 2, 3, 4, 0, 0, 0], dtype=torch.int64), world)
+        assert c[0] == sum(10 + r for r in range(world)) and c[1] == world
+        el, ks = bench.reduce_times(0.5 + rank, 0.25 * (rank + 1), world, torch.device("cpu"))
+        assert el == 0.5 + world - 1 and ks == 0.25 * world
+        if rank == 0:
+            frame = np.zeros_like(gold)
+            for r in range(world):
+                n = int(counts[r])
+                rtx.scatter_tiles(frame, parts[r][:n * W * 3].numpy().reshape(n, W, 3), r, world, tile_rows)
+            assert np.array_equal(frame, gold)
+        scene.close()
+        q.put((rank, "ok"))
+    except Exception as e:  # surfaced in the parent
+        q.put((rank, "FAIL %r" % (e,)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_rows", [(2, 8), (2, 5), (3, 16)])
+def test_gloo_ranks_shard_gather_reduce(world, tile_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, tile_rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_tile_partition_is_exact_cover():
+    rtx = importlib.import_module("ray-tracer-rust_amd")
+    with open(os.path.join(GOLD, "golden.json")) as f:
+        case = json.load(f)["cases"][NAME]
+    scene = rtx.default_scene([os.path.join(ROOT, "models", "big_bunny.obj")], case["width"], case["height"],
+                              rtx.gen_samples(n_pairs=1024), tie_rank=None)
+    H = case["height"]
+    for world in (1, 2, 3, 4, 8):
+        for tile_rows in (1, 3, 8, 16, 117, 500):
+            seen = np.zeros(H, int)
+            total = 0
+            for rank in range(world):
+                rows = scene.tiles_rows(rank, world, tile_rows)
+                total += rows
+                t = rank
+                n = 0
+                while t * tile_rows < H:
+                    seen[t * tile_rows:(t + 1) * tile_rows] += 1
+                    n += min(tile_rows, H - t * tile_rows)
+                    assert rtx.tile_owner(t, world) == rank
+                    t += world
+                assert n == rows
+            assert total == H and (seen == 1).all()
+    scene.close()
