@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 1
+#define RTX_ABI_VERSION 2
 
 typedef enum RtxError {
     RTX_OK              =  0,
@@ -56,6 +56,17 @@ typedef enum RtxError {
 #define RTX_ACCEL_BVH    0u  /* SAH BVH over the triangles' AABBs, wave-uniform traversal (default) */
 #define RTX_ACCEL_BRUTE  1u  /* one leaf holding every triangle: brute-force scan                    */
 
+/* The reference's own tree (BoundingVolumeHierarchy::new, bounding_volume_hierarchy.rs:173-226; O(n^2)).
+ * It is NOT the traversal structure: for rays whose direction components are all non-zero the
+ * result provably does not depend on the tree.  It is needed for two corner
+ * cases, which is why the library rebuilds it on the host: exact-distance ties (the right-most leaf
+ * wins) and rays with a zero direction component, whose result in the reference depends on the tree
+ * (a -0.0 component rejects an ancestor box through +-inf while a flat leaf box accepts through
+ * ignored NaNs); wavefronts holding such a ray are traced against the reference tree itself. */
+#define RTX_REFTREE_AUTO   0u  /* build it when n_tris <= 50,000 (beyond that the reference cannot run) */
+#define RTX_REFTREE_ALWAYS 1u
+#define RTX_REFTREE_NEVER  2u  /* ties: tie_rank or index order; zero-component rays: the library's tree */
+
 /*
  * Flat description of the reference's Scene (src/tracer/utils/scene.rs:6-12):
  *   width,height           Scene.width/height
@@ -68,8 +79,10 @@ typedef enum RtxError {
  *                          leaf order of the reference BVH.  When two triangles are hit at exactly
  *                          the same distance the reference returns the right-most one
  *                          (bounding_volume_hierarchy.rs:123-130); the library returns the one with
- *                          the larger tie_rank.  NULL = rank is the index.  rtxh_ref_leaf_rank
+ *                          the larger tie_rank.  NULL = taken from the reference tree when the
+ *                          library builds it (reference_tree), else the index.  rtxh_ref_leaf_rank
  *                          computes it (restates bounding_volume_hierarchy.rs:173-226).
+ *   reference_tree         RTX_REFTREE_*
  *   nb_ray,nb_light_sample NB_RAY / NB_LIGHT_SAMPLE (src/main.rs:38-39)
  *   samples,n_samples      the random-sample table, n_samples pairs (s.0,s.1) interleaved
  *                          (src/main.rs:253,262-265); NB_RAND_SAMPLE = 2,000,000 in the reference
@@ -88,6 +101,7 @@ typedef struct RtxSceneDesc {
     uint32_t n_samples;
     uint32_t accel;             /* RTX_ACCEL_* */
     uint32_t leaf_max;          /* max triangles per BVH leaf; 0 = library default */
+    uint32_t reference_tree;    /* RTX_REFTREE_* */
 } RtxSceneDesc;
 
 typedef struct RtxStats {
@@ -99,6 +113,7 @@ typedef struct RtxStats {
     uint64_t tri_tests;         /* ray-triangle Möller–Trumbore tests executed (per lane)       */
     uint64_t wave_node_visits;  /* BVH node records fetched (per wave)                          */
     uint64_t wave_tri_visits;   /* triangle records fetched (per wave)                          */
+    uint64_t redo_tiles;        /* 8x8 tiles re-rendered with the literal reference traversal   */
     double   kernel_ms;         /* hipEvent time of the kernel(s) of this call                  */
     double   total_ms;          /* host wall time of the call (launch + D2H + gather)           */
 } RtxStats;
@@ -106,6 +121,8 @@ typedef struct RtxStats {
 typedef struct RtxSceneInfo {
     uint32_t n_tris, n_nodes, n_leaves, max_leaf_tris, depth;
     uint32_t n_light_points;
+    uint32_t n_ref_nodes;       /* records of the reference-tree stream (0 = not built) */
+    uint32_t reserved;
     uint64_t node_bytes, tri_bytes, shade_bytes, sample_bytes;
 } RtxSceneInfo;
 
@@ -142,7 +159,8 @@ int rtx_render_frame(RtxScene *scene, const int *devices, int n_devices, uint32_
  * (device pointer, d_out_bytes >= rtx_tiles_bytes(...)).  The launch is asynchronous on
  * `stream` (a hipStream_t; NULL = the default stream); inputs must already be uploaded or are
  * uploaded synchronously first.  d_counters: NULL, or a device buffer of 8 uint64 that the kernel
- * ADDS its counters to (primary_hits, box_tests, tri_tests, wave_node_visits, wave_tri_visits). */
+ * ADDS its counters to (primary_hits, box_tests, tri_tests, wave_node_visits, wave_tri_visits, redo_tiles).
+ * Launches on one device must be ordered on one stream (the library keeps a per-device work queue). */
 int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, uint32_t tile_stride,
                             uint32_t tile_rows, void *d_out_rgb, size_t d_out_bytes,
                             void *stream, uint64_t *d_counters);
@@ -168,6 +186,8 @@ int rtx_scene_gamma_thresholds(const RtxScene *scene, float *out256);
 int rtx_scene_normals(const RtxScene *scene, float *out);
 /* the traversal stream: node records (8 dwords each) and the triangle order of the leaves */
 int rtx_scene_nodes(const RtxScene *scene, uint32_t *out_dwords /* n_nodes*8 */, uint32_t *out_tri_order /* n_tris */);
+/* the reference-tree stream (n_ref_nodes*8 dwords; leaf info = 0x80000000 | position in out_tri_order) */
+int rtx_scene_ref_nodes(const RtxScene *scene, uint32_t *out_dwords);
 
 /* ---- host helpers: the caller side of the seam, restated (rtxh_*) ---------- */
 /* Camera::new, src/tracer/utils/camera.rs:17-35 */

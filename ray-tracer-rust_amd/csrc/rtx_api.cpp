@@ -35,12 +35,14 @@ thread_local int g_last_hip_error = 0;
 struct DeviceState {
     std::mutex mu;
     bool uploaded = false;
-    void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr;
+    void *nodes = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_out = nullptr;
     size_t d_out_cap = 0;
     unsigned long long *d_counters = nullptr;
+    uint32_t *d_redo = nullptr;   // queue of tiles for reference_tiles_kernel
+    size_t d_redo_cap = 0;
     uint8_t *h_stage = nullptr;   // pinned
     size_t h_stage_cap = 0;
 };
@@ -118,6 +120,7 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     const rtx::PreparedScene &p = scene->prep;
     int rc;
     if ((rc = upload_vec(&st.nodes, p.nodes, sizeof(rtx::NodeRec))) != RTX_OK) return rc;
+    if (!p.ref_nodes.empty() && (rc = upload_vec(&st.ref_nodes, p.ref_nodes, sizeof(rtx::NodeRec))) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.tris, p.tris)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.shade, p.shade)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.samples, p.samples)) != RTX_OK) return rc;
@@ -137,6 +140,8 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     const rtx::PreparedScene &p = scene->prep;
     rtx::DeviceScene S;
     S.nodes = static_cast<const rtx::NodeRec *>(st.nodes);
+    S.ref_nodes = static_cast<const rtx::NodeRec *>(st.ref_nodes);
+    S.n_ref_nodes = static_cast<uint32_t>(p.ref_nodes.size());
     S.tris = static_cast<const rtx::TriRec *>(st.tris);
     S.shade = static_cast<const rtx::ShadeRec *>(st.shade);
     S.samples = static_cast<const float2 *>(st.samples);
@@ -175,6 +180,18 @@ int ensure_out(DeviceState &st, size_t bytes, bool need_stage)
     return RTX_OK;
 }
 
+// the redo queue of a launch (rtx_device.h); grows only
+int ensure_redo(DeviceState &st, size_t bytes)
+{
+    if (st.d_redo_cap >= bytes) return RTX_OK;
+    if (st.d_redo) RTX_HIP(hipFree(st.d_redo));
+    st.d_redo = nullptr;
+    st.d_redo_cap = 0;
+    RTX_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_redo), bytes));
+    st.d_redo_cap = bytes;
+    return RTX_OK;
+}
+
 uint32_t tiles_rows(uint32_t height, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows)
 {
     if (!tile_rows || !tile_stride) return 0;
@@ -198,6 +215,7 @@ void fill_stats(RtxStats *s, const RtxScene *scene, uint64_t pixels, const unsig
     s->tri_tests = c[2];
     s->wave_node_visits = c[3];
     s->wave_tri_visits = c[4];
+    s->redo_tiles = c[5];
     s->kernel_ms = kernel_ms;
     s->total_ms = total_ms;
 }
@@ -209,10 +227,12 @@ int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool co
     if (rc != RTX_OK) return rc;
     const size_t bytes = static_cast<size_t>(ts.local_rows) * scene->prep.width * 3u;
     if ((rc = ensure_out(st, bytes ? bytes : 16, stage)) != RTX_OK) return rc;
+    const rtx::DeviceScene S = device_scene(scene, st);
+    if ((rc = ensure_redo(st, rtx::trace_redo_bytes(S, ts))) != RTX_OK) return rc;
     if (count)
         RTX_HIP(hipMemsetAsync(st.d_counters, 0, rtx::kNumCounters * sizeof(unsigned long long), st.stream));
     RTX_HIP(hipEventRecord(st.ev0, st.stream));
-    RTX_HIP(rtx::launch_trace_shade(device_scene(scene, st), ts, st.d_out, count ? st.d_counters : nullptr, nullptr,
+    RTX_HIP(rtx::launch_trace_shade(S, ts, st.d_out, st.d_redo, count ? st.d_counters : nullptr, nullptr,
                                     kernel_variant(), st.stream));
     RTX_HIP(hipEventRecord(st.ev1, st.stream));
     return RTX_OK;
@@ -268,7 +288,7 @@ void rtx_scene_destroy(RtxScene *scene)
         DeviceGuard g(kv.first);
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
-        void *bufs[] = {st.nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters};
+        void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters, st.d_redo};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);
         if (st.ev0) (void)hipEventDestroy(st.ev0);
@@ -288,6 +308,8 @@ int rtx_scene_info(const RtxScene *scene, RtxSceneInfo *info)
     info->max_leaf_tris = p.max_leaf_tris;
     info->depth = p.depth;
     info->n_light_points = p.nb_ray * p.nb_light_sample;
+    info->n_ref_nodes = static_cast<uint32_t>(p.ref_nodes.size());
+    info->reserved = 0;
     info->node_bytes = p.nodes.size() * sizeof(rtx::NodeRec);
     info->tri_bytes = p.tris.size() * sizeof(rtx::TriRec);
     info->shade_bytes = p.shade.size() * sizeof(rtx::ShadeRec);
@@ -428,7 +450,10 @@ int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, ui
     RTX_HIP(g.status());
     if ((rc = ensure_uploaded(scene, *st)) != RTX_OK) return rc;
     const rtx::TileSpec ts{first_tile * tile_rows, tile_rows, tile_stride * tile_rows, rows};
-    RTX_HIP(rtx::launch_trace_shade(device_scene(scene, *st), ts, static_cast<uint8_t *>(d_out_rgb),
+    const rtx::DeviceScene S = device_scene(scene, *st);
+    // the redo queue is library-owned per device: launches on one device must be ordered on one stream
+    if ((rc = ensure_redo(*st, rtx::trace_redo_bytes(S, ts))) != RTX_OK) return rc;
+    RTX_HIP(rtx::launch_trace_shade(S, ts, static_cast<uint8_t *>(d_out_rgb), st->d_redo,
                                     reinterpret_cast<unsigned long long *>(d_counters), nullptr, kernel_variant(),
                                     static_cast<hipStream_t>(stream)));
     return RTX_OK;
@@ -458,7 +483,9 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     RTX_HIP(hipMalloc(reinterpret_cast<void **>(&d_prof), n * 4 * sizeof(unsigned long long)));
     hipError_t e = hipMemsetAsync(d_prof, 0, n * 4 * sizeof(unsigned long long), st->stream);
     const rtx::TileSpec ts{row0, nrows, nrows, nrows};
-    if (e == hipSuccess) e = rtx::launch_trace_shade(S, ts, st->d_out, nullptr, d_prof, kernel_variant(), st->stream);
+    if (ensure_redo(*st, rtx::trace_redo_bytes(S, ts)) != RTX_OK) { (void)hipFree(d_prof); return RTX_ERR_OOM; }
+    if (e == hipSuccess)
+        e = rtx::launch_trace_shade(S, ts, st->d_out, st->d_redo, nullptr, d_prof, kernel_variant(), st->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_prof, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(st->stream);
     (void)hipFree(d_prof);
@@ -485,6 +512,13 @@ int rtx_scene_normals(const RtxScene *scene, float *out)
 {
     if (!scene || !out) return RTX_ERR_BAD_ARG;
     for (size_t i = 0; i < scene->prep.shade.size(); ++i) std::memcpy(out + 3 * i, scene->prep.shade[i].normal, 12);
+    return RTX_OK;
+}
+
+int rtx_scene_ref_nodes(const RtxScene *scene, uint32_t *out_dwords)
+{
+    if (!scene || !out_dwords) return RTX_ERR_BAD_ARG;
+    std::memcpy(out_dwords, scene->prep.ref_nodes.data(), scene->prep.ref_nodes.size() * sizeof(rtx::NodeRec));
     return RTX_OK;
 }
 

@@ -13,12 +13,13 @@ namespace rtx {
 // Passed by value (kernarg segment -> SGPRs).
 struct DeviceScene {
     const NodeRec  *nodes;         // (n_nodes + 1) x 32 B, pre-order with skip links; last = zeroed sentinel
+    const NodeRec  *ref_nodes;     // (n_ref_nodes + 1) x 32 B: the reference's own tree, or NULL
     const TriRec   *tris;          // n_tris x 64 B, leaf order
     const ShadeRec *shade;         // n_tris x 32 B, caller order
     const float2   *samples;       // n_samples x (s.0, s.1)
     const float    *light_points;  // nb_ray x nb_light x 3
     const float    *gamma_thr;     // 256
-    uint32_t n_nodes, n_samples;
+    uint32_t n_nodes, n_ref_nodes, n_samples;
     uint32_t width, height;
     uint32_t nb_ray, nb_light;
     float eye[3], cu[3], cv[3], cw[3];
@@ -49,7 +50,10 @@ constexpr uint32_t kDefaultVariant = 3u;
 // d_wave_prof: NULL or 4 uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end (100 MHz ticks)},
 // zero-initialised by the caller, row-major over tiles with trace_tiles_x() tiles per row.
 uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
-hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out,
+// d_redo: device queue of tiles to re-render with the literal reference traversal: [0] = length, then
+// tile ids; trace_redo_bytes() is its size for a launch.  Reset and consumed inside the launch.
+size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts);
+hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                               unsigned long long *d_counters, unsigned long long *d_wave_prof,
                               uint32_t variant, hipStream_t stream);
 

@@ -1,0 +1,296 @@
+// rtx_traverse.hpp — device-side closest-hit traversal for the gfx950 tracer kernels (rtx_kernel.hip).
+//
+// Closest hit (BVHNode::intersect, bounding_volume_hierarchy.rs:50-143; citations are path:line in the
+// reference repository)
+//   The acceleration structure is a pre-order, skip-linked BVH stream (scene_prep.h).  A
+//   wavefront walks it as ONE traversal: the node index lives in a scalar register, node and
+//   triangle records arrive through scalar (SMEM) loads and are consumed as SGPR operands, and
+//   the 64 lanes test their own rays against the same box / triangle.  A subtree is skipped
+//   only when NO lane's box test passes (wave ballot), so control flow never diverges and no
+//   per-lane stack exists.  Lanes apply the reference's leaf rule themselves: a triangle hit
+//   counts only if the ray also passes that triangle's own AABB with the reference's exact slab
+//   arithmetic (bvh.rs:52) and t >= 1.0 (bvh.rs:64-67).  Because the reference never prunes by
+//   distance, every node whose box passes is visited here too; the result is the minimum over
+//   the same candidate set.
+//
+//   Inner-node culling only has to be CONSERVATIVE (never reject a box the exact test accepts):
+//   slab_fast() replaces the six IEEE divisions by multiplications with 1/d and widens the
+//   interval by 2^-20 relative + 2^-100 absolute, which covers the <= 3*2^-24 relative
+//   difference between fl(a*fl(1/d)) and fl(a/d) (DESIGN.md "Conservative culling").
+//
+//   All of the above holds for rays whose direction components are regular (non-zero, normal,
+//   finite).  Rays with a zero component are outside it — the reference's result then depends on
+//   its own tree — and are traced by closest_hit_reference() against that tree.
+//
+// Arithmetic
+//   IEEE binary32, one rounding per operation, in the reference's operation order; compiled
+//   with -ffp-contract=off and correctly rounded division / square root (hipcc default).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "rtx_device.h"
+
+namespace rtx {
+
+#define RTX_CONSTANT __attribute__((address_space(4)))
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr float kOccluded = -1.0f;   // |n.l| is never negative; marks an occluded sample in LDS
+
+struct WaveCounters {
+    unsigned long long box_tests = 0, tri_tests = 0, node_visits = 0, tri_visits = 0;
+};
+
+// BoundingBox::intersect as a predicate — bounding_box.rs:99-181.  Branch-free restatement:
+// the early `return None`s become masks, the values computed after them are unused there.
+__device__ __forceinline__ bool slab_exact(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                           float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const bool inside = ox > lox && ox < hix && oy > loy && oy < hiy && oz > loz && oz < hiz;   // :104-108
+    const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
+    float tmin = ((px ? lox : hix) - ox) / dx;                                                   // :120-127
+    float tmax = ((px ? hix : lox) - ox) / dx;
+    const float tymin = ((py ? loy : hiy) - oy) / dy;                                            // :129-136
+    const float tymax = ((py ? hiy : loy) - oy) / dy;
+    const bool miss_xy = tmin > tymax || tymin > tmax;                                           // :138-140
+    tmin = tymin > tmin ? tymin : tmin;                                                          // :142-144
+    tmax = tymax < tmax ? tymax : tmax;                                                          // :146-148
+    const float tzmin = ((pz ? loz : hiz) - oz) / dz;                                            // :150-157
+    const float tzmax = ((pz ? hiz : loz) - oz) / dz;
+    const bool miss_z = tmin > tzmax || tzmin > tmax;                                            // :159-161
+    tmin = tzmin > tmin ? tzmin : tmin;                                                          // :163-165
+    tmax = tzmax < tmax ? tzmax : tmax;                                                          // :167-169
+    const bool ok = tmin < FLT_MAX && tmax > 0.0f;                                               // :171
+    return inside || (!miss_xy && !miss_z && ok);
+}
+
+// Conservative superset of slab_exact for rays whose direction components are all finite and of
+// magnitude >= 2^-60 (so 1/d is finite and no product is NaN).  ix,iy,iz = 1/d (IEEE division).
+//   exact   q = fl(fl(p-o)/d)          mine  t = fl(fl(p-o)*fl(1/d)),  |t-q| <= 3*2^-24 |q| (+ underflow)
+// near/far per axis = min/max of the two products (same planes as the sign-of-d selection), entry =
+// max of nears, exit = min of fars; the exact test passes only if every near <= every far and every
+// far > 0, so rejecting only when entry exceeds exit by more than the widening, or exit is clearly
+// negative, never rejects a box the exact test accepts (also covers its origin-inside shortcut:
+// then every near <= 0 <= every far).
+__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                          float ox, float oy, float oz, float ix, float iy, float iz)
+{
+    const float ax = (lox - ox) * ix, bx = (hix - ox) * ix;
+    const float ay = (loy - oy) * iy, by = (hiy - oy) * iy;
+    const float az = (loz - oz) * iz, bz = (hiz - oz) * iz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, 0x1p-100f);
+    return !(t_in - t_out > slack) && !(t_out < -0x1p-100f);   // written so that a NaN can only accept
+}
+
+// a node record through the constant address space (scalar loads); field-wise because a struct copy
+// across address spaces has no implicit constructor
+__device__ __forceinline__ NodeRec load_node(const NodeRec RTX_CONSTANT *p)
+{
+    NodeRec r;
+    r.bmin[0] = p->bmin[0]; r.bmin[1] = p->bmin[1]; r.bmin[2] = p->bmin[2];
+    r.link = p->link;
+    r.bmax[0] = p->bmax[0]; r.bmax[1] = p->bmax[1]; r.bmax[2] = p->bmax[2];
+    r.info = p->info;
+    return r;
+}
+
+// Direction classes (per component c of the unit direction):
+//   regular   2^-60 <= |c| <= 2          1/c finite, every slab term finite: multiply-based culling is valid
+//   soft      +0.0, or 0 < |c| < 2^-60   slab terms may be +-inf (and NaN only where the origin lies exactly on
+//                                        a box face), but a +0.0 divisor keeps them ORDERED like the planes, so a
+//                                        ray that passes a box still passes every enclosing box: the result is
+//                                        tree-independent with the exact slab arithmetic
+//   hard      -0.0, NaN, inf             (p-o)/(-0.0) flips the infinities: an enclosing box can reject what the
+//                                        leaf accepts; the reference's result depends on its own tree
+__device__ __forceinline__ bool direction_is_regular(float dx, float dy, float dz)
+{
+    // every comparison with a NaN is false
+    return fabsf(dx) >= 0x1p-60f && fabsf(dx) <= 2.0f && fabsf(dy) >= 0x1p-60f && fabsf(dy) <= 2.0f &&
+           fabsf(dz) >= 0x1p-60f && fabsf(dz) <= 2.0f;
+}
+
+__device__ __forceinline__ bool component_is_soft_or_regular(float c)
+{
+    return c == 0.0f ? __float_as_uint(c) == 0u : fabsf(c) <= 2.0f;
+}
+
+__device__ __forceinline__ bool direction_is_hard(float dx, float dy, float dz)
+{
+    return !(component_is_soft_or_regular(dx) && component_is_soft_or_regular(dy) && component_is_soft_or_regular(dz));
+}
+
+// The literal reference traversal, for wavefronts that hold a ray with a zero / denormal / non-finite
+// direction component.  For such rays BoundingBox::intersect produces +-inf and NaN (0/0) terms and
+// the outcome depends on the tree: e.g. with d.y = -0.0 an ancestor box gives tymin=+inf, tymax=-inf
+// and rejects, while a flat leaf box at the origin's height gives NaN, NaN, which the comparisons
+// ignore.  So these rays walk a stream of the reference's OWN tree (ref_tree_build) and every lane
+// keeps the reference's per-ray state: a lane whose box test failed at a node is dead until the walk
+// leaves that subtree (`resume`), exactly as BVHNode::intersect returns None without visiting the
+// children (bvh.rs:52-55,136-141).  Leaves are met in the reference's left-to-right order, so
+// "take when t <= best" is the fold of its "left only if strictly less" rule (:123-130).
+// When the reference tree was not built (RTX_REFTREE_NEVER / too many primitives) the same walk runs
+// on the library's tree, with ties by rank.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_reference(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                                    const TriRec RTX_CONSTANT *__restrict__ tris,
+                                                    const ShadeRec *__restrict__ shade, uint32_t n_nodes,
+                                                    bool dfs_ties, bool active, float ox, float oy, float oz,
+                                                    float dx, float dy, float dz,
+                                                    float &best_t, uint32_t &best_idx, WaveCounters &wc)
+{
+    best_t = __builtin_inff();
+    best_idx = kNone;
+    unsigned long long n_active = 0;
+    if (COUNT) n_active = __popcll(__ballot(active));
+    uint32_t resume = 0;   // per lane: first stream position at which this lane is alive again
+    uint32_t i = 0;
+    while (i < n_nodes) {
+        const NodeRec cur = load_node(nodes + i);
+        const bool leaf = (cur.info & kLeafFlag) != 0u;
+        const uint32_t after = leaf ? i + 1u : cur.link;
+        const bool live = active && i >= resume;
+        const bool pass = live && slab_exact(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1],
+                                             cur.bmax[2], ox, oy, oz, dx, dy, dz);               // bvh.rs:52
+        if (live && !pass) resume = after;
+        const bool any = __ballot(pass) != 0ull;
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+        if (leaf && any) {
+            const uint32_t first = cur.info & ~kLeafFlag;
+            for (uint32_t k = 0; k < cur.link; ++k) {
+                const TriRec RTX_CONSTANT *tr = tris + (first + k);
+                const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
+                const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
+                if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+                const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+                const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                const bool parallel = det < 0.00001f && det > -0.00001f;
+                const float inv = 1.0f / det;
+                const float tvx = ox - tr->v0[0], tvy = oy - tr->v0[1], tvz = oz - tr->v0[2];
+                const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;
+                const bool out_u = u < 0.0f || u > 1.0f;
+                const float qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;
+                const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;
+                const bool out_v = v < 0.0f || u + v > 1.0f;
+                const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;
+                if (pass && !parallel && !out_u && !out_v && !(t < 1.0f)) {
+                    // multi-triangle leaves (library tree): the triangle's own box still gates it; on the
+                    // reference stream the leaf box is this box and the test repeats with the same result
+                    if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
+                                   ox, oy, oz, dx, dy, dz)) {
+                        const uint32_t idx = tr->idx;
+                        bool take;
+                        if (dfs_ties) {
+                            take = t <= best_t;
+                        } else {
+                            take = t < best_t;
+                            if (!take && t == best_t && best_idx != kNone) take = shade[idx].rank > shade[best_idx].rank;
+                        }
+                        if (take) { best_t = t; best_idx = idx; }
+                    }
+                }
+            }
+        }
+        i = (any || leaf) ? i + 1u : cur.link;
+    }
+}
+
+// One wave-uniform closest-hit traversal.  `active` lanes carry a ray; the others never vote.
+// best_t / best_idx: minimum accepted distance and the caller-order index of its triangle.
+// Valid for rays whose direction components are all regular (direction_is_regular): then every term of
+// the slab test is finite, the test is monotone in the box, and the result does not depend on the tree.
+// Returns false (and traces nothing) when an active lane's direction is hard: the tile is then re-rendered
+// by reference_tiles_kernel.  A wavefront holding a soft direction uses the exact slab test for this
+// traversal (the multiply-based culling needs finite 1/d).
+template <bool COUNT, bool FAST>
+__device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                            const TriRec RTX_CONSTANT *__restrict__ tris,
+                                            const ShadeRec *__restrict__ shade, uint32_t n_nodes,
+                                            bool active, float ox, float oy, float oz,
+                                            float dx, float dy, float dz,
+                                            float &best_t, uint32_t &best_idx, WaveCounters &wc)
+{
+    best_t = __builtin_inff();
+    best_idx = kNone;
+    if (__ballot(active && direction_is_hard(dx, dy, dz)) != 0ull) return false;
+    const bool use_fast = FAST && __ballot(active && !direction_is_regular(dx, dy, dz)) == 0ull;
+    unsigned long long n_active = 0;
+    if (COUNT) n_active = __popcll(__ballot(active));
+
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+    if (use_fast) {
+        ix = 1.0f / dx;
+        iy = 1.0f / dy;
+        iz = 1.0f / dz;
+    }
+
+    uint32_t i = 0;
+    while (i < n_nodes) {
+        const NodeRec cur = load_node(nodes + i);
+        const bool leaf = (cur.info & kLeafFlag) != 0u;
+        bool pass;
+        if (use_fast)
+            pass = slab_fast(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
+                             ox, oy, oz, ix, iy, iz);
+        else
+            pass = slab_exact(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
+                              ox, oy, oz, dx, dy, dz);
+        const bool any = __ballot(active && pass) != 0ull;
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+
+        if (leaf && any) {
+            const uint32_t first = cur.info & ~kLeafFlag;
+            const uint32_t count = cur.link;
+            for (uint32_t k = 0; k < count; ++k) {
+                const TriRec RTX_CONSTANT *tr = tris + (first + k);
+                const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
+                const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
+                const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
+                if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+                // Triangle::intersect — triangle.rs:66-94
+                const float pvx = dy * e2z - dz * e2y;                                   // :69
+                const float pvy = dz * e2x - dx * e2z;
+                const float pvz = dx * e2y - dy * e2x;
+                const float det = e1x * pvx + e1y * pvy + e1z * pvz;                     // :70
+                const bool parallel = det < 0.00001f && det > -0.00001f;                 // :73
+                const float inv = 1.0f / det;                                            // :77
+                const float tvx = ox - v0x, tvy = oy - v0y, tvz = oz - v0z;              // :78
+                const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;               // :79
+                const bool out_u = u < 0.0f || u > 1.0f;                                 // :80
+                const float qvx = tvy * e1z - tvz * e1y;                                 // :84
+                const float qvy = tvz * e1x - tvx * e1z;
+                const float qvz = tvx * e1y - tvy * e1x;
+                const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;                  // :85
+                const bool out_v = v < 0.0f || u + v > 1.0f;                             // :86
+                const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;               // :92
+                const bool some = !parallel && !out_u && !out_v;
+                // leaf rule: x < 1.0 -> None (bvh.rs:64-67)
+                if (active && some && !(t < 1.0f)) {
+                    // the leaf's own box gates the triangle test in the reference (bvh.rs:52): exact arithmetic
+                    if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
+                                   ox, oy, oz, dx, dy, dz)) {
+                        const uint32_t idx = tr->idx;
+                        bool take = t < best_t;
+                        if (!take && t == best_t && best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
+                            take = shade[idx].rank > shade[best_idx].rank;
+                        if (take) { best_t = t; best_idx = idx; }
+                    }
+                }
+            }
+        }
+        // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
+        i = (any || leaf) ? i + 1u : cur.link;
+    }
+    return true;
+}
+
+}  // namespace
+
+}  // namespace rtx

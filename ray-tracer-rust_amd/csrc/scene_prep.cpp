@@ -129,13 +129,18 @@ int build_gamma_thresholds(float thr[256])
     return RTX_OK;
 }
 
-// Leaf order of BoundingVolumeHierarchy::new — bounding_volume_hierarchy.rs:173-226.
-// Needed only to reproduce which of two exactly-equidistant triangles the reference
-// returns (the right-most leaf, :123-130).  Clusters by bbox *extent* because
-// get_center() returns max-min (bounding_box.rs:183-189); O(n^2) per level like the original.
-int ref_leaf_rank(uint32_t n, const float *v0v1v2, uint32_t *out_rank)
+// The reference's own tree — BoundingVolumeHierarchy::new, bounding_volume_hierarchy.rs:173-226.
+// Clusters by bbox *extent* because get_center() returns max-min (bounding_box.rs:183-189); O(n^2)
+// per level like the original.  Two things need it:
+//   - the left-to-right leaf order decides which of two exactly-equidistant triangles the reference
+//     returns (the right-most leaf, :123-130)  -> out_rank;
+//   - for rays with a zero direction component the reference's result depends on the tree itself (a
+//     -0.0 component makes an ancestor's slab test reject through +-inf while a flat leaf accepts
+//     through ignored NaNs), so those rays are traced against THIS tree -> out_stream: pre-order,
+//     skip-linked NodeRecs, one triangle per leaf, leaf info = kLeafFlag | caller index.
+int ref_tree_build(uint32_t n, const float *v0v1v2, uint32_t *out_rank, std::vector<NodeRec> *out_stream)
 {
-    if (!n || !v0v1v2 || !out_rank) return RTX_ERR_BAD_ARG;
+    if (!n || !v0v1v2) return RTX_ERR_BAD_ARG;
     struct Cluster { float lo[3], hi[3]; int32_t left, right; };   // left < 0: leaf
     std::vector<Cluster> pool;
     pool.reserve(2 * static_cast<size_t>(n));
@@ -190,18 +195,45 @@ int ref_leaf_rank(uint32_t n, const float *v0v1v2, uint32_t *out_rank)
         if (level.size() == 1) next.push_back(level[0]);  // odd one out goes last
         level.swap(next);
     }
-    // left-to-right leaf walk, iterative
-    std::vector<int32_t> stack{level[0]};
+    // pre-order walk, left before right (the order BVHNode::intersect recurses in, :88-107)
+    if (out_stream) { out_stream->clear(); out_stream->reserve(pool.size()); }
+    struct Frame { int32_t id; uint32_t pos; bool done; };
+    std::vector<Frame> stack{{level[0], 0u, false}};
     uint32_t rank = 0;
     while (!stack.empty()) {
-        const int32_t id = stack.back();
+        Frame f = stack.back();
         stack.pop_back();
-        const Cluster &c = pool[id];
-        if (c.left < 0) { out_rank[c.right] = rank++; continue; }
-        stack.push_back(c.right);
-        stack.push_back(c.left);
+        const Cluster &c = pool[f.id];
+        if (f.done) {   // subtree finished: the skip link of this inner node is the next position
+            if (out_stream) (*out_stream)[f.pos].link = static_cast<uint32_t>(out_stream->size());
+            continue;
+        }
+        NodeRec rec;
+        std::memcpy(rec.bmin, c.lo, 12);
+        std::memcpy(rec.bmax, c.hi, 12);
+        const uint32_t pos = out_stream ? static_cast<uint32_t>(out_stream->size()) : 0u;
+        if (c.left < 0) {
+            rec.info = kLeafFlag | static_cast<uint32_t>(c.right);
+            rec.link = 1;
+            if (out_stream) out_stream->push_back(rec);
+            if (out_rank) out_rank[c.right] = rank;
+            ++rank;
+            continue;
+        }
+        rec.info = 0;
+        rec.link = 0;
+        if (out_stream) out_stream->push_back(rec);
+        stack.push_back({f.id, pos, true});
+        stack.push_back({c.right, 0u, false});
+        stack.push_back({c.left, 0u, false});
     }
     return rank == n ? RTX_OK : RTX_ERR_INTERNAL;
+}
+
+int ref_leaf_rank(uint32_t n, const float *v0v1v2, uint32_t *out_rank)
+{
+    if (!out_rank) return RTX_ERR_BAD_ARG;
+    return ref_tree_build(n, v0v1v2, out_rank, nullptr);
 }
 
 // --------------------------------------------------------------------------
@@ -357,7 +389,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
 {
     if (!d.width || !d.height || !d.n_tris || !d.v0v1v2 || !d.rgb || !d.samples || !d.n_samples || !d.nb_ray)
         return RTX_ERR_BAD_ARG;
-    if (d.n_tris >= 0x40000000u || d.accel > RTX_ACCEL_BRUTE) return RTX_ERR_BAD_ARG;
+    if (d.n_tris >= 0x40000000u || d.accel > RTX_ACCEL_BRUTE || d.reference_tree > RTX_REFTREE_NEVER) return RTX_ERR_BAD_ARG;
     if (static_cast<uint64_t>(d.width) * d.height >= (1ull << 31)) return RTX_ERR_BAD_ARG;
 
     s.width = d.width;
@@ -387,6 +419,17 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
         const int grc = build_gamma_thresholds(s.gamma_thr);
         if (grc != RTX_OK) return grc;
 
+        // the reference's own tree (see ref_tree_build): ranks for exact ties, stream for irregular rays
+        std::vector<uint32_t> ref_rank;
+        s.ref_nodes.clear();
+        const bool want_ref = d.reference_tree == RTX_REFTREE_ALWAYS ||
+                              (d.reference_tree == RTX_REFTREE_AUTO && d.n_tris <= kRefTreeAutoMax);
+        if (want_ref) {
+            ref_rank.resize(d.n_tris);
+            const int rrc = ref_tree_build(d.n_tris, d.v0v1v2, ref_rank.data(), &s.ref_nodes);
+            if (rrc != RTX_OK) return rrc;
+        }
+
         std::vector<Prim> prims(d.n_tris);
         std::vector<TriRec> recs(d.n_tris);   // caller order for now
         s.shade.resize(d.n_tris);
@@ -400,7 +443,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             triangle_derive(t, t + 3, t + 6, r.e1, r.e2, sh.normal, r.bmin, r.bmax);
             r.idx = i;
             std::memcpy(sh.rgb, d.rgb + 3 * static_cast<size_t>(i), 12);
-            sh.rank = d.tie_rank ? d.tie_rank[i] : i;
+            sh.rank = d.tie_rank ? d.tie_rank[i] : (want_ref ? ref_rank[i] : i);
             sh.pad = 0;
             Prim &p = prims[i];
             for (int k = 0; k < 3; ++k) {
@@ -438,7 +481,13 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             s.depth = tb.depth;
         }
         s.tris.resize(d.n_tris);
-        for (uint32_t i = 0; i < d.n_tris; ++i) s.tris[i] = recs[prims[i].idx];
+        std::vector<uint32_t> pos_of(d.n_tris);
+        for (uint32_t i = 0; i < d.n_tris; ++i) {
+            s.tris[i] = recs[prims[i].idx];
+            pos_of[prims[i].idx] = i;
+        }
+        for (NodeRec &nd : s.ref_nodes)   // leaves of the reference stream point at the same TriRec array
+            if (nd.info & kLeafFlag) nd.info = kLeafFlag | pos_of[nd.info & ~kLeafFlag];
     } catch (const std::bad_alloc &) {
         return RTX_ERR_OOM;
     }

@@ -59,6 +59,7 @@ struct PreparedScene {
     uint32_t n_tris = 0;
     uint32_t n_samples = 0;
     std::vector<NodeRec>  nodes;
+    std::vector<NodeRec>  ref_nodes;   // the reference's own tree as a stream (empty when not built)
     std::vector<TriRec>   tris;        // in leaf order
     std::vector<ShadeRec> shade;       // in caller order
     std::vector<float>    samples;     // n_samples x 2
@@ -80,5 +81,8 @@ void light_sample(const float v0[3], const float v1[3], const float v2[3], float
 uint8_t gamma_quantise(float linear);
 int  build_gamma_thresholds(float thr[256]);
 int  ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank);
+int  ref_tree_build(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank, std::vector<NodeRec> *out_stream);
+// above this many primitives RTX_REFTREE_AUTO skips the O(n^2) reference tree (the reference itself could not build it)
+constexpr uint32_t kRefTreeAutoMax = 50000u;
 
 }  // namespace rtx

@@ -99,9 +99,9 @@ struct Light {
 namespace utils {
 
 // Owns the primitive list, like the reference's BVH owns its Vec<Primitive> (it is consumed by
-// BoundingVolumeHierarchy::new, src/main.rs:357).  create() also derives the reference tree's
-// leaf order, which decides exact-distance ties (bounding_volume_hierarchy.rs:123-130); the
-// traversal structure itself is built inside the library for the GPU.
+// BoundingVolumeHierarchy::new, src/main.rs:357).  Both trees — the GPU traversal structure and the
+// reference's own tree, which decides exact-distance ties and zero-component rays — are built inside
+// the library from this list (rtx_scene_create).
 class BoundingVolumeHierarchy {
 public:
     static BoundingVolumeHierarchy create(std::vector<primitives::Primitive> prims, int *err = nullptr)
@@ -116,25 +116,15 @@ public:
             const float c[3] = {t->color.red, t->color.green, t->color.blue};
             b.rgb_.insert(b.rgb_.end(), c, c + 3);
         }
-        if (rc == RTX_OK && !prims.empty()) {
-            b.rank_.resize(prims.size());
-            // O(n^2) like the reference's own constructor; beyond what the reference could build, skip
-            if (prims.size() <= 50000)
-                rc = rtxh_ref_leaf_rank(static_cast<uint32_t>(prims.size()), b.v0v1v2_.data(), b.rank_.data());
-            else
-                b.rank_.clear();
-        }
         if (err) *err = rc;
         return b;
     }
     uint32_t len() const { return static_cast<uint32_t>(rgb_.size() / 3); }
     const float *vertices() const { return v0v1v2_.data(); }
     const float *colors() const { return rgb_.data(); }
-    const uint32_t *tie_rank() const { return rank_.empty() ? nullptr : rank_.data(); }
 
 private:
     std::vector<float> v0v1v2_, rgb_;
-    std::vector<uint32_t> rank_;
 };
 
 struct Scene {
@@ -201,7 +191,8 @@ inline int render(const utils::Scene &scene, const std::vector<std::pair<float, 
     d.n_tris = scene.bvh.len();
     d.v0v1v2 = scene.bvh.vertices();
     d.rgb = scene.bvh.colors();
-    d.tie_rank = scene.bvh.tie_rank();
+    d.tie_rank = nullptr;                    // taken from the reference tree the library rebuilds
+    d.reference_tree = RTX_REFTREE_AUTO;
     d.nb_ray = nb_ray;
     d.nb_light_sample = nb_light_sample;
     d.samples = reinterpret_cast<const float *>(samples.data());

@@ -25,6 +25,7 @@ _lib = C.CDLL(LIB_PATH)
 
 OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL, ERR_IO = 0, -1, -2, -3, -4, -5, -6, -7
 ACCEL_BVH, ACCEL_BRUTE = 0, 1
+REFTREE_AUTO, REFTREE_ALWAYS, REFTREE_NEVER = 0, 1, 2
 
 # constants of the reference: src/main.rs:38-40
 NB_RAY, NB_LIGHT_SAMPLE, NB_RAND_SAMPLE = 1, 100, 2000000
@@ -56,21 +57,22 @@ class SceneDesc(C.Structure):
         ("v0v1v2", f32p), ("rgb", f32p), ("tie_rank", u32p),
         ("nb_ray", C.c_uint32), ("nb_light_sample", C.c_uint32),
         ("samples", f32p), ("n_samples", C.c_uint32),
-        ("accel", C.c_uint32), ("leaf_max", C.c_uint32),
+        ("accel", C.c_uint32), ("leaf_max", C.c_uint32), ("reference_tree", C.c_uint32),
     ]
 
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "primary_rays", "primary_hits", "shadow_rays", "rays", "box_tests", "tri_tests",
-        "wave_node_visits", "wave_tri_visits")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+        "wave_node_visits", "wave_tri_visits", "redo_tiles")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class SceneInfo(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("n_tris", "n_nodes", "n_leaves", "max_leaf_tris", "depth", "n_light_points")] + \
+    _fields_ = [(n, C.c_uint32) for n in ("n_tris", "n_nodes", "n_leaves", "max_leaf_tris", "depth", "n_light_points",
+                                          "n_ref_nodes", "reserved")] + \
                [(n, C.c_uint64) for n in ("node_bytes", "tri_bytes", "shade_bytes", "sample_bytes")]
 
     def asdict(self):
@@ -98,6 +100,7 @@ _SIGS = {
     "rtx_scene_gamma_thresholds": (C.c_int, [C.c_void_p, f32p]),
     "rtx_scene_normals": (C.c_int, [C.c_void_p, f32p]),
     "rtx_scene_nodes": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "rtx_scene_ref_nodes": (C.c_int, [C.c_void_p, u32p]),
     "rtxh_camera_new": (None, [f32p] * 6),
     "rtxh_import_obj": (C.c_int, [C.c_char_p, C.POINTER(f32p)]),
     "rtxh_free": (None, [C.c_void_p]),
@@ -198,7 +201,8 @@ class Scene:
 
     def __init__(self, width, height, tris, rgb, samples, *, eye=DEFAULT_EYE, look_at=DEFAULT_LOOK_AT,
                  up=DEFAULT_UP, distance=DEFAULT_DISTANCE, light_tri=DEFAULT_LIGHT, nb_ray=NB_RAY,
-                 nb_light_sample=NB_LIGHT_SAMPLE, accel=ACCEL_BVH, leaf_max=0, tie_rank="reference"):
+                 nb_light_sample=NB_LIGHT_SAMPLE, accel=ACCEL_BVH, leaf_max=0, tie_rank="reference",
+                 reference_tree=REFTREE_AUTO):
         self._h = C.c_void_p()
         self.width, self.height = int(width), int(height)
         self.tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
@@ -209,10 +213,11 @@ class Scene:
         if isinstance(tie_rank, str):
             if tie_rank != "reference":
                 raise ValueError(tie_rank)
-            # BoundingVolumeHierarchy::new is O(n^2): only worth it where the reference itself could run
-            rank = ref_leaf_rank(self.tris) if len(self.tris) <= 50000 else None
+            rank = None          # the library derives it from the reference tree it builds (reference_tree)
         else:
             rank = None if tie_rank is None else np.ascontiguousarray(tie_rank, dtype=np.uint32)
+            if tie_rank is None and reference_tree == REFTREE_AUTO:
+                reference_tree = REFTREE_NEVER   # tie_rank=None means "index order, no reference tree"
         self.tie_rank = rank
         u, v, w = camera_new(eye, look_at, up)
         lt = np.asarray(light_tri, dtype=np.float32).reshape(9)
@@ -227,7 +232,7 @@ class Scene:
         d.tie_rank = rank.ctypes.data_as(u32p) if rank is not None else None
         d.nb_ray, d.nb_light_sample = int(nb_ray), int(nb_light_sample)
         d.samples, d.n_samples = _fp(self.samples), len(self.samples)
-        d.accel, d.leaf_max = int(accel), int(leaf_max)
+        d.accel, d.leaf_max, d.reference_tree = int(accel), int(leaf_max), int(reference_tree)
         _check(_lib.rtx_scene_create(C.byref(d), C.byref(self._h)), "rtx_scene_create")
 
     # -- lifetime
@@ -280,6 +285,12 @@ class Scene:
         order = np.zeros(i["n_tris"], np.uint32)
         _check(_lib.rtx_scene_nodes(self._h, nd.ctypes.data_as(u32p), order.ctypes.data_as(u32p)), "rtx_scene_nodes")
         return nd, order
+
+    def ref_nodes(self):
+        nd = np.zeros((self.info()["n_ref_nodes"], 8), np.uint32)
+        if len(nd):
+            _check(_lib.rtx_scene_ref_nodes(self._h, nd.ctypes.data_as(u32p)), "rtx_scene_ref_nodes")
+        return nd
 
     # -- rendering (GPU only)
     def upload(self, device=0):

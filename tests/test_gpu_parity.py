@@ -163,7 +163,8 @@ def test_exact_tie_returns_reference_leaf(rtx, orc, samples_seeded):
     winner = int(otri[H // 2, W // 2])
     assert osc.leaf_order()[-1] == winner
     with rtx.Scene(W, H, tris, rgb, samples_seeded, **kw) as s:
-        assert np.array_equal(np.argsort(s.tie_rank), osc.leaf_order())
+        assert np.array_equal(np.argsort(rtx.ref_leaf_rank(tris)), osc.leaf_order())
+        assert s.info()["n_ref_nodes"] == 2 * len(tris) - 1
         img = s.render_rows()
     assert_image_close(img, ref, "tie scene")
     lit = img[H // 2, W // 2].astype(int)
@@ -212,3 +213,42 @@ def test_full_size_1080p_properties(rtx, orc, samples_seeded, samples_half):
     assert st3["primary_hits"] == 1022304
     ref, _ = orc.default_scene(["bunny.obj"], W, H, samples_half).render_rows(800, 2, mode=orc.MODE_BVH)
     assert_image_close(img3[800:802], ref, "bunny.obj 1080p")
+
+
+def _random_soup(rng, n, lattice):
+    """Triangles with vertices on an integer lattice (many exactly axis-aligned edges / flat boxes /
+    shared planes) or at random float positions."""
+    if lattice:
+        v = rng.integers(-6, 7, size=(n, 3, 3)).astype(np.float32)
+        v[..., 2] -= 14.0
+    else:
+        c = rng.uniform(-6, 6, size=(n, 1, 3)).astype(np.float32)
+        c[..., 2] -= 14.0
+        v = c + rng.uniform(-2.5, 2.5, size=(n, 3, 3)).astype(np.float32)
+    e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    keep = np.linalg.norm(np.cross(e1, e2), axis=1) > 1e-3          # drop zero-area (NaN normals)
+    v = v[keep]
+    rgb = rng.uniform(0.2, 1.0, size=(len(v), 3)).astype(np.float32)
+    return v.reshape(-1, 9), rgb
+
+
+@pytest.mark.parametrize("seed,lattice,table", [(1, True, "zero"), (2, True, "zero"), (3, True, "seed"),
+                                                (4, False, "seed"), (5, False, "zero"), (6, True, "half")])
+def test_random_soups_including_degenerate_rays(rtx, orc, samples_seeded, samples_half, seed, lattice, table):
+    """Random triangle soups seen by an axis-aligned camera at the origin.  With an all-zero sample table the
+    primary directions are (px-W/2, -(py-H/2), -d)/norm: exact zeros on the centre row and column, origin
+    coordinates equal to lattice box faces -> the 0/0 and +-inf corners of the slab test, and the wave-wide
+    switch from the multiply-based culling to the exact test.  GPU must equal the oracle's faithful BVH."""
+    rng = np.random.default_rng(seed)
+    tris, rgb = _random_soup(rng, 300, lattice)
+    T = {"zero": np.zeros((4096, 2), np.float32), "seed": samples_seeded, "half": samples_half}[table]
+    kw = dict(eye=(0.0, 0.0, 0.0), look_at=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), distance=24.0,
+              light_tri=(-2.0, 9.0, -3.0, 2.0, 9.0, -3.0, 0.0, 9.0, 1.0), nb_light_sample=24)
+    W, H = 40, 40
+    ref, ost, otri = orc.Scene(W, H, tris, rgb, T, **kw).render_rows(mode=orc.MODE_BVH, want_tri=True)
+    assert ost["nonfinite_t"] == 0 and ost["primary_hits"] > 100
+    with rtx.Scene(W, H, tris, rgb, T, **kw) as s:
+        img, st = s.render_rows(stats=True)
+    assert st["primary_hits"] == ost["primary_hits"]
+    nz = assert_image_close(img, ref, "soup seed %d" % seed)
+    assert nz == 0

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(rtx):
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert declared <= exported, declared - exported
     assert declared == set(rtx.rtx._SIGS), declared ^ set(rtx.rtx._SIGS)     # the binding covers the whole header
-    assert rtx.abi_version() == 1
+    assert rtx.abi_version() == 2
     assert rtx.device_count() >= 0
 
 
@@ -254,3 +254,23 @@ def test_png_writer_roundtrip(rtx, tmp_path):
         rtx.write_png(p, img)
         back = np.asarray(Image.open(p))
         assert back.shape == img.shape and np.array_equal(back, img)
+
+
+def test_reference_tree_stream(rtx, orc, samples_half):
+    """The stream of the reference's own tree (used for zero-component rays): 2n-1 records, well formed,
+    its leaves in the oracle tree's left-to-right order, and ranks derived from it when tie_rank is NULL."""
+    tris, rgb = rtx.default_primitives([model("big_bunny.obj")])
+    osc = orc.Scene(8, 8, tris, rgb, samples_half[:16])
+    with rtx.Scene(32, 32, tris, rgb, samples_half[:64]) as s:
+        info = s.info()
+        assert info["n_ref_nodes"] == 2 * len(tris) - 1 == osc.node_count()
+        ref = s.ref_nodes()
+        _, order = s.nodes()
+        _check_stream(ref, order, tris, len(tris))
+        leaves = ref[(ref[:, 7] & 0x80000000) != 0]
+        assert (leaves[:, 3] == 1).all()
+        assert np.array_equal(order[leaves[:, 7] & 0x7FFFFFFF], osc.leaf_order())
+    with rtx.Scene(32, 32, tris, rgb, samples_half[:64], reference_tree=rtx.REFTREE_NEVER) as s:
+        assert s.info()["n_ref_nodes"] == 0 and len(s.ref_nodes()) == 0
+    with rtx.Scene(32, 32, tris[:50], rgb[:50], samples_half[:64], tie_rank=None) as s:
+        assert s.info()["n_ref_nodes"] == 0          # tie_rank=None: index order, no reference tree

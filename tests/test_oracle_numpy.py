@@ -109,3 +109,45 @@ def test_primary_hit_mask_1080p_matches_survey_probe(orc, samples_half):
     s2 = orc.Scene(1920, 1080, tris2, rgb2, samples_half, nb_light_sample=0)
     _, st2, tri2 = s2.render_rows(mode=orc.MODE_BVH, want_tri=True)
     assert st2["mesh_hits"] == 0 and (tri2 == len(tris2) - 1).sum() == 1022304
+
+
+def test_tree_dependence_is_confined_to_negative_zero_directions(orc):
+    """Where the faithful BVH and the leaf-gated brute force DISAGREE.  With a -0.0 direction component the slab
+    test of an enclosing box divides by -0.0 and rejects through +-inf, while a flat leaf box at the origin's
+    coordinate produces NaNs that the comparisons ignore — the reference's result then depends on its tree.
+    This scene (integer lattice, eye on the lattice, all-zero jitter) produces such rays on the centre row;
+    every pixel on which the two strategies differ must carry a -0.0 component, and rays with a +0.0
+    component must agree (the GPU path relies on exactly this split, rtx_traverse.hpp)."""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    v = rng.integers(-6, 7, size=(300, 3, 3)).astype(np.float32)
+    v[..., 2] -= 14.0
+    keep = np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1) > 1e-3
+    tris = v[keep].reshape(-1, 9)
+    rgb = np.ones((len(tris), 3), np.float32)
+    T = np.zeros((4096, 2), np.float32)
+    kw = dict(eye=(0.0, 0.0, 0.0), look_at=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), distance=24.0,
+              light_tri=(-2.0, 9.0, -3.0, 2.0, 9.0, -3.0, 0.0, 9.0, 1.0), nb_light_sample=0)
+    W = H = 40
+    s = orc.Scene(W, H, tris, rgb, T, **kw)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    cam = [np.zeros(3, np.float32) for _ in range(3)]
+    orc.lib().orc_camera_new(fp(orc.f3(kw["eye"])), fp(orc.f3(kw["look_at"])), fp(orc.f3(kw["up"])), *map(fp, cam))
+    n_neg = n_pos = n_diff = 0
+    for py in range(H):
+        for px in range(W):
+            o, d = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            orc.lib().orc_create_ray(px, py, 0, W, H, fp(orc.f3(kw["eye"])), fp(cam[0]), fp(cam[1]), fp(cam[2]),
+                                     24.0, fp(T), len(T), fp(o), fp(d))
+            neg_zero = bool(((d == 0) & np.signbit(d)).any())
+            pos_zero = bool(((d == 0) & ~np.signbit(d)).any())
+            a = s.closest_hit(o, d, orc.MODE_BVH)
+            b = s.closest_hit(o, d, orc.MODE_LEAFBOX)
+            same = (a.hit, a.t if a.hit else 0.0) == (b.hit, b.t if b.hit else 0.0)
+            n_neg += neg_zero
+            n_pos += pos_zero and not neg_zero
+            if not same:
+                n_diff += 1
+                assert neg_zero, (px, py, d)
+    assert n_neg >= W // 2 - 1 and n_pos >= H // 2      # both kinds of ray are present in the scene
+    print("rays with -0.0: %d, with only +0.0: %d, BVH != LEAFBOX on %d" % (n_neg, n_pos, n_diff))
