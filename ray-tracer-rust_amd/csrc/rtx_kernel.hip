@@ -34,6 +34,13 @@ namespace rtx {
 
 namespace {
 
+// phase-2 ray numbering for tiles whose hit pixels all lie on one triangle (see the kernel); a switch so
+// that the profile can show what it is worth
+#ifndef RTX_ONE_SURFACE_SAMPLE_MAJOR
+#define RTX_ONE_SURFACE_SAMPLE_MAJOR 1
+#endif
+constexpr bool kOneSurfaceSampleMajor = RTX_ONE_SURFACE_SAMPLE_MAJOR != 0;
+
 // byte of a linear channel: number of thresholds (b >= 1) that are <= x  (color.rs:28-33)
 __device__ __forceinline__ uint32_t quantise(const float *__restrict__ thr, float x)
 {
@@ -160,13 +167,21 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
                 h[3] = sh.normal[0]; h[4] = sh.normal[1]; h[5] = sh.normal[2];        // main.rs:206
                 cr = sh.rgb[0]; cg = sh.rgb[1]; cb = sh.rgb[2];                       // main.rs:191
             }
+            // Ray numbering of phase 2.  All hit pixels on ONE triangle (the ground, a wall): the 64 pixels of a
+            // sample make the tighter shaft (neighbouring surface points -> one light point), number sample-major.
+            // Several triangles (mesh surface, silhouettes): origins sit in different BVH leaves, a pixel's own
+            // samples (one origin -> the small light) are tighter, number pixel-major.
+            const uint32_t first_idx = __builtin_amdgcn_readfirstlane(hit_mask ? __shfl(idx, __ffsll((long long)hit_mask) - 1) : 0u);
+            const bool one_surface = __ballot(hit && idx != first_idx) == 0ull;
             if (lane == 0) {
                 l_ctl[0] = (uint32_t)__popcll(hit_mask);
                 if (!ok) l_ctl[1] = 1u;
+                l_ctl[2] = (kOneSurfaceSampleMajor && one_surface) ? 1u : 0u;
             }
         }
         __syncthreads();
         const uint32_t n_hit = __builtin_amdgcn_readfirstlane(l_ctl[0]);
+        const bool sample_major = __builtin_amdgcn_readfirstlane(l_ctl[2]) != 0u;
         if (n_hit != 0u) {                                                            // else main.rs:235
             for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                     // main.rs:193, in batches that fit LDS
                 const uint32_t bc = (S.nb_light - b0 < batch) ? S.nb_light - b0 : batch;
@@ -180,8 +195,11 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
                 for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                     const uint32_t ray = c0 + lane;
                     const bool valid = ray < total;
-                    const uint32_t hp = valid ? ray / bc : 0u;
-                    const uint32_t si = valid ? ray - hp * bc : 0u;
+                    const uint32_t div = sample_major ? n_hit : bc;
+                    const uint32_t quo = valid ? ray / div : 0u;
+                    const uint32_t rem = valid ? ray - quo * div : 0u;
+                    const uint32_t hp = sample_major ? rem : quo;     // compacted hit pixel
+                    const uint32_t si = sample_major ? quo : rem;     // light sample within the batch
                     const float *h = l_hit + 8u * hp;
                     const float hx = h[0], hy = h[1], hz = h[2];
                     const float vx = l_light[3u * si] - hx, vy = l_light[3u * si + 1u] - hy,
