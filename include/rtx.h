@@ -168,9 +168,11 @@ int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, ui
 uint32_t rtx_tiles_rows(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows);
 size_t   rtx_tiles_bytes(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows);
 
-/* Diagnostics: per 8x8 pixel tile of rows [row0,row0+nrows), 4 uint64 {node records fetched, triangle
- * records fetched, start, end} with start/end in ticks of the 100 MHz device wall clock.  Call with
+/* Diagnostics: per 8x8 pixel tile of rows [row0,row0+nrows), RTX_WAVE_PROFILE_WORDS uint64 {node records
+ * fetched, triangle records fetched, start, end, primary phase, shadow phase (slowest wavefront),
+ * accumulation phase, reserved}, times in ticks of the 100 MHz device wall clock.  Call with
  * out == NULL to get the tile grid (*tiles_x, *tiles_y); out_tiles = capacity of out in tiles. */
+#define RTX_WAVE_PROFILE_WORDS 8
 int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t nrows, uint64_t *out,
                            size_t out_tiles, uint32_t *tiles_x, uint32_t *tiles_y);
 

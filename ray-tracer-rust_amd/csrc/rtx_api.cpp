@@ -480,17 +480,19 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     if (out_tiles < n) return RTX_ERR_BAD_ARG;
     if ((rc = ensure_out(*st, static_cast<size_t>(nrows) * scene->prep.width * 3u, false)) != RTX_OK) return rc;
     unsigned long long *d_prof = nullptr;
-    RTX_HIP(hipMalloc(reinterpret_cast<void **>(&d_prof), n * 4 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d_prof, 0, n * 4 * sizeof(unsigned long long), st->stream);
+    const size_t prof_bytes = n * rtx::kWaveProfWords * sizeof(unsigned long long);
+    RTX_HIP(hipMalloc(reinterpret_cast<void **>(&d_prof), prof_bytes));
+    hipError_t e = hipMemsetAsync(d_prof, 0, prof_bytes, st->stream);
     const rtx::TileSpec ts{row0, nrows, nrows, nrows};
     if (ensure_redo(*st, rtx::trace_redo_bytes(S, ts)) != RTX_OK) { (void)hipFree(d_prof); return RTX_ERR_OOM; }
     if (e == hipSuccess)
         e = rtx::launch_trace_shade(S, ts, st->d_out, st->d_redo, nullptr, d_prof, kernel_variant(), st->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_prof, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_prof, prof_bytes, hipMemcpyDeviceToHost, st->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(st->stream);
     (void)hipFree(d_prof);
     RTX_HIP(e);
-    for (size_t t = 0; t < n; ++t) out[4 * t + 2] = ~out[4 * t + 2];   // the kernel keeps the earliest start as max(~t)
+    for (size_t t = 0; t < n; ++t)   // the kernel keeps the earliest start as max(~t)
+        out[rtx::kWaveProfWords * t + 2] = ~out[rtx::kWaveProfWords * t + 2];
     return RTX_OK;
 }
 

@@ -47,8 +47,10 @@ constexpr uint32_t kMaxLightBatch = 128u;
 // bits 1-2 = wavefronts per workgroup: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1.
 constexpr uint32_t kDefaultVariant = 3u;
 
-// d_wave_prof: NULL or 4 uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end (100 MHz ticks)},
+// d_wave_prof: NULL or kWaveProfWords uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end, primary
+// phase, slowest wave's shadow phase, accumulation phase, -} in ticks of the 100 MHz wall clock;
 // zero-initialised by the caller, row-major over tiles with trace_tiles_x() tiles per row.
+constexpr size_t kWaveProfWords = 8;
 uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
 // d_redo: device queue of tiles to re-render with the literal reference traversal: [0] = length, then
 // tile ids; trace_redo_bytes() is its size for a launch.  Reset and consumed inside the launch.

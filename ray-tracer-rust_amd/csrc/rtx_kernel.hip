@@ -40,6 +40,9 @@ namespace {
 #define RTX_ONE_SURFACE_SAMPLE_MAJOR 1
 #endif
 constexpr bool kOneSurfaceSampleMajor = RTX_ONE_SURFACE_SAMPLE_MAJOR != 0;
+#ifndef RTX_WAVES_PER_SIMD
+#define RTX_WAVES_PER_SIMD 8
+#endif
 
 // byte of a linear channel: number of thresholds (b >= 1) that are <= x  (color.rs:28-33)
 __device__ __forceinline__ uint32_t quantise(const float *__restrict__ thr, float x)
@@ -112,8 +115,10 @@ __device__ __forceinline__ void flush_counters(unsigned long long *__restrict__ 
 __host__ __device__ inline uint32_t lds_res_stride(uint32_t batch) { return batch | 1u; }   // odd: conflict-free column reads
 __host__ __device__ inline uint32_t lds_floats(uint32_t batch) { return 3u * batch + 64u * 8u + 64u * lds_res_stride(batch) + 4u; }
 
+// Second launch bound = wavefronts per SIMD the register allocation must allow: 8 (64 VGPRs) for the
+// shipped kernel — the traversal is a chain of dependent scalar loads, resident waves are what hides it.
 template <bool COUNT, bool FAST, int NW>
-__global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch,
+__global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD) trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch,
                                                                uint8_t *__restrict__ out, uint32_t *__restrict__ redo,
                                                                unsigned long long *__restrict__ counters,
                                                                unsigned long long *__restrict__ wave_prof)
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
     uint32_t px, py, ly;
     const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
 
-    unsigned long long t_start = 0;
+    unsigned long long t_start = 0, t_mark = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0;   // diagnostics (COUNT builds)
     if (COUNT) t_start = wall_clock64();
     WaveCounters wc;
     unsigned long long primary_hits = 0;
@@ -151,6 +156,7 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
         if (wave == 0) {
             float dx, dy, dz, t;
             uint32_t idx;
+            if (COUNT) t_mark = wall_clock64();
             primary_ray(S, in_frame, px, py, r, dx, dy, dz);
             const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1],
                                                      S.eye[2], dx, dy, dz, t, idx, wc);   // main.rs:187
@@ -178,6 +184,7 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
                 if (!ok) l_ctl[1] = 1u;
                 l_ctl[2] = (kOneSurfaceSampleMajor && one_surface) ? 1u : 0u;
             }
+            if (COUNT) t_ph1 += wall_clock64() - t_mark;
         }
         __syncthreads();
         const uint32_t n_hit = __builtin_amdgcn_readfirstlane(l_ctl[0]);
@@ -192,6 +199,7 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
 
                 // ------------- phase 2: shadow rays, one work-item per (hit pixel, sample) -------------
                 const uint32_t total = n_hit * bc;
+                if (COUNT) t_mark = wall_clock64();
                 for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                     const uint32_t ray = c0 + lane;
                     const bool valid = ray < total;
@@ -219,9 +227,11 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
                     }
                     if (valid) l_res[hp * res_stride + si] = lit ? lnd : kOccluded;
                 }
+                if (COUNT) t_ph2 += wall_clock64() - t_mark;
                 __syncthreads();
 
                 // ------------- phase 3: ordered accumulation, one work-item per pixel (wave 0) -------------
+                if (COUNT) t_mark = wall_clock64();
                 if (wave == 0 && hit) {
                     const float *res = l_res + slot * res_stride;
                     for (uint32_t i = 0; i < bc; ++i) {                               // i ascending, main.rs:209-216
@@ -233,6 +243,7 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
                         }
                     }
                 }
+                if (COUNT && wave == 0) t_ph3 += wall_clock64() - t_mark;
                 __syncthreads();   // results and light points are overwritten by the next batch / ray
             }
         }
@@ -254,11 +265,14 @@ __global__ void __launch_bounds__(64 * NW) trace_shade_kernel(DeviceScene S, Til
     if (COUNT && lane == 0) {
         flush_counters<COUNT>(counters, primary_hits, wc);
         if (wave_prof) {   // diagnostics: per-tile work and residency (rtx_debug_wave_profile); zeroed by the host
-            unsigned long long *p = wave_prof + 4ull * ((unsigned long long)tile_y * gridDim.x + tile_x);
+            unsigned long long *p = wave_prof + 8ull * ((unsigned long long)tile_y * gridDim.x + tile_x);
             atomicAdd(&p[0], wc.node_visits);
             atomicAdd(&p[1], wc.tri_visits);
             atomicMax(&p[2], ~t_start);   // stored inverted so that a zeroed buffer works as the identity
             atomicMax(&p[3], (unsigned long long)wall_clock64());
+            atomicMax(&p[4], t_ph1);      // wave 0: primary rays
+            atomicMax(&p[5], t_ph2);      // slowest wave: shadow rays
+            atomicMax(&p[6], t_ph3);      // wave 0: ordered accumulation
         }
     }
 }

@@ -314,13 +314,14 @@ class Scene:
         return (out, st.asdict()) if stats else out
 
     def wave_profile(self, row0=0, nrows=None, device=0):
-        """Diagnostics: [tiles_y, tiles_x, 4] uint64 {node fetches, triangle fetches, start, end (100 MHz ticks)}."""
+        """Diagnostics: [tiles_y, tiles_x, 8] uint64 {node fetches, triangle fetches, start, end, primary phase,
+        shadow phase (slowest wavefront), accumulation phase, -}; times in 100 MHz ticks."""
         if nrows is None:
             nrows = self.height - row0
         tx, ty = C.c_uint32(), C.c_uint32()
         _check(_lib.rtx_debug_wave_profile(self._h, device, row0, nrows, None, 0, C.byref(tx), C.byref(ty)),
                "rtx_debug_wave_profile")
-        out = np.zeros((ty.value, tx.value, 4), np.uint64)
+        out = np.zeros((ty.value, tx.value, 8), np.uint64)
         _check(_lib.rtx_debug_wave_profile(self._h, device, row0, nrows, out.ctypes.data_as(u64p), tx.value * ty.value,
                                            C.byref(tx), C.byref(ty)), "rtx_debug_wave_profile")
         return out

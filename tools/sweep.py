@@ -94,6 +94,17 @@ def main():
         for q in (0.5, 0.8, 0.9, 0.95, 0.99, 1.0):
             print("  %3.0f%% of tiles finished by %.0f us; started by %.0f us" % (
                 q * 100, np.quantile(end, q), np.quantile(start, q)))
+        ph = prof[..., 4:7].astype(np.float64) / 100.0                      # us: primary, shadow (slowest wave), accumulate
+        tot = ph.sum(axis=(0, 1))
+        print("phase time summed over tiles (us): primary %.0f  shadow %.0f  accumulate %.0f  | residency %.0f" % (
+            tot[0], tot[1], tot[2], dur.sum()))
+        heavy = dur > np.percentile(dur, 90)
+        th = ph[heavy].sum(axis=0)
+        print("heaviest 10%% of tiles: primary %.1f%%  shadow %.1f%%  accumulate %.1f%% of their residency" % tuple(
+            100 * th / dur[heavy].sum()))
+        shadow_tiles = ph[..., 1] > 0
+        print("tiles with shadow work %d: median us primary %.1f shadow %.1f accumulate %.1f" % (
+            shadow_tiles.sum(), *np.median(ph[shadow_tiles], axis=0)))
         rows = work.sum(axis=1)
         print("work by tile row (top 10):", np.argsort(rows)[::-1][:10].tolist())
 
