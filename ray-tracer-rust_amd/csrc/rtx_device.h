@@ -52,8 +52,10 @@ constexpr uint32_t kDefaultVariant = 3u;
 // zero-initialised by the caller, row-major over tiles with trace_tiles_x() tiles per row.
 constexpr size_t kWaveProfWords = 8;
 uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
-// d_redo: device queue of tiles to re-render with the literal reference traversal: [0] = length, then
-// tile ids; trace_redo_bytes() is its size for a launch.  Reset and consumed inside the launch.
+// d_redo: the device work queue of a launch: [kQueueRedoCount] = number of tiles queued for the literal
+// reference traversal, [kQueueNextTile] = next tile the persistent workgroups pull, tile ids from
+// [kQueueHeader]; trace_redo_bytes() is its size for a launch.  Reset and consumed inside the launch.
+constexpr uint32_t kQueueRedoCount = 0u, kQueueNextTile = 1u, kQueueHeader = 4u;
 size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts);
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                               unsigned long long *d_counters, unsigned long long *d_wave_prof,

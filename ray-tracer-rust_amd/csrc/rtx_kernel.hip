@@ -87,6 +87,47 @@ __device__ __forceinline__ void primary_ray(const DeviceScene &S, bool in_frame,
     dz = rz / rn;
 }
 
+// One shadow ray of phase 2: ray number -> (compacted hit pixel, light sample), origin = the pixel's hit
+// point, direction = towards the light point (main.rs:194-202).
+struct ShadowRay {
+    LaneRay ray;
+    uint32_t hp, si;
+    float dist_light;
+};
+
+__device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit, const float *__restrict__ l_light,
+                                                uint32_t ray, uint32_t total, uint32_t div, bool sample_major)
+{
+    ShadowRay s;
+    const bool valid = ray < total;
+    const uint32_t quo = valid ? ray / div : 0u;
+    const uint32_t rem = valid ? ray - quo * div : 0u;
+    s.hp = sample_major ? rem : quo;     // compacted hit pixel
+    s.si = sample_major ? quo : rem;     // light sample within the batch
+    const float *h = l_hit + 8u * s.hp;
+    const float hx = h[0], hy = h[1], hz = h[2];
+    const float vx = l_light[3u * s.si] - hx, vy = l_light[3u * s.si + 1u] - hy, vz = l_light[3u * s.si + 2u] - hz;   // p - orig
+    s.dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                               // main.rs:202
+    s.ray = make_ray(valid, hx, hy, hz, vx / s.dist_light, vy / s.dist_light, vz / s.dist_light);   // main.rs:201
+    return s;
+}
+
+// |n.l| when the sample is lit, the marker when it is occluded (main.rs:206-232)
+__device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, float *__restrict__ l_res,
+                                              uint32_t res_stride, const ShadowRay &s)
+{
+    const float *h = l_hit + 8u * s.hp;
+    const LaneRay &r = s.ray;
+    const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
+    bool lit = true;                                                                  // main.rs:229-231
+    if (r.best_idx != kNone) {                                                        // main.rs:219-227
+        const float qx = r.ox - (r.ox + r.best_t * r.dx), qy = r.oy - (r.oy + r.best_t * r.dy),
+                    qz = r.oz - (r.oz + r.best_t * r.dz);
+        lit = sqrtf(qx * qx + qy * qy + qz * qz) > s.dist_light;
+    }
+    if (r.active) l_res[s.hp * res_stride + s.si] = lit ? lnd : kOccluded;
+}
+
 __device__ __forceinline__ void store_pixel(const DeviceScene &S, uint8_t *__restrict__ out, uint32_t px, uint32_t ly,
                                             float r, float g, float b)
 {
@@ -118,10 +159,10 @@ __host__ __device__ inline uint32_t lds_floats(uint32_t batch) { return 3u * bat
 // Second launch bound = wavefronts per SIMD the register allocation must allow: 8 (64 VGPRs) for the
 // shipped kernel — the traversal is a chain of dependent scalar loads, resident waves are what hides it.
 template <bool COUNT, bool FAST, int NW>
-__global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD) trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch,
-                                                               uint8_t *__restrict__ out, uint32_t *__restrict__ redo,
-                                                               unsigned long long *__restrict__ counters,
-                                                               unsigned long long *__restrict__ wave_prof)
+__global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD)
+trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x, uint32_t tiles_y,
+                   uint8_t *__restrict__ out, uint32_t *__restrict__ queue,
+                   unsigned long long *__restrict__ counters, unsigned long long *__restrict__ wave_prof)
 {
     extern __shared__ __align__(16) float lds[];
     float *const l_light = lds;
@@ -135,19 +176,33 @@ __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD) trace
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile_x = blockIdx.x;
-    const uint32_t tile_y = gridDim.y - 1u - blockIdx.y;   // heavy rows (ground, bottom of the frame) first
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    WaveCounters wc;
+    unsigned long long primary_hits_total = 0;
+    const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
+
+    // Persistent workgroups: the grid holds only as many workgroups as the chip keeps resident; each pulls
+    // tiles from a device counter until it runs past the end (every wavefront reaches that exit).  Tiles are
+    // numbered bottom row first: the ground rows are the heavy ones, the sky rows on top fill the tail.
+    for (;;) {
+    if (threadIdx.x == 0) {
+        l_ctl[3] = atomicAdd(&queue[kQueueNextTile], 1u);
+        l_ctl[1] = 0u;
+    }
+    __syncthreads();
+    const uint32_t q = __builtin_amdgcn_readfirstlane(l_ctl[3]);
+    if (q >= n_tiles) break;
+    const uint32_t tile_x = q % tiles_x;
+    const uint32_t tile_y = tiles_y - 1u - q / tiles_x;
     uint32_t px, py, ly;
     const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
 
     unsigned long long t_start = 0, t_mark = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0;   // diagnostics (COUNT builds)
     if (COUNT) t_start = wall_clock64();
-    WaveCounters wc;
     unsigned long long primary_hits = 0;
-    if (threadIdx.x == 0) l_ctl[1] = 0u;
+    const unsigned long long nv0 = wc.node_visits, tv0 = wc.tri_visits;
 
     float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;                                  // main.rs:182 (wave 0 only)
-    const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         // ---------------- phase 1: primary rays, one work-item per pixel (wave 0) ----------------
         bool hit = false;
@@ -158,8 +213,10 @@ __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD) trace
             uint32_t idx;
             if (COUNT) t_mark = wall_clock64();
             primary_ray(S, in_frame, px, py, r, dx, dy, dz);
-            const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, in_frame, S.eye[0], S.eye[1],
-                                                     S.eye[2], dx, dy, dz, t, idx, wc);   // main.rs:187
+            LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
+            const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
+            t = pr.best_t;
+            idx = pr.best_idx;
             hit = in_frame && idx != kNone;
             const unsigned long long hit_mask = __ballot(hit);
             slot = __popcll(hit_mask & ((1ull << lane) - 1ull));                      // compacted index of this pixel
@@ -200,46 +257,52 @@ __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD) trace
                 // ------------- phase 2: shadow rays, one work-item per (hit pixel, sample) -------------
                 const uint32_t total = n_hit * bc;
                 if (COUNT) t_mark = wall_clock64();
+                const uint32_t div = sample_major ? n_hit : bc;
+                // (two chunks per wavefront at a time — two rays per lane, both node loads in flight — was measured
+                //  slower, 4.3 vs 3.7 ms on C3: it needs ~105 VGPRs, and resident wavefronts hide more latency)
                 for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
-                    const uint32_t ray = c0 + lane;
-                    const bool valid = ray < total;
-                    const uint32_t div = sample_major ? n_hit : bc;
-                    const uint32_t quo = valid ? ray / div : 0u;
-                    const uint32_t rem = valid ? ray - quo * div : 0u;
-                    const uint32_t hp = sample_major ? rem : quo;     // compacted hit pixel
-                    const uint32_t si = sample_major ? quo : rem;     // light sample within the batch
-                    const float *h = l_hit + 8u * hp;
-                    const float hx = h[0], hy = h[1], hz = h[2];
-                    const float vx = l_light[3u * si] - hx, vy = l_light[3u * si + 1u] - hy,
-                                vz = l_light[3u * si + 2u] - hz;                       // p - orig
-                    const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);      // main.rs:202
-                    const float sx = vx / dist_light, sy = vy / dist_light, sz = vz / dist_light;   // main.rs:201
-                    float st;
-                    uint32_t sidx;
-                    const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, valid, hx, hy, hz,
-                                                             sx, sy, sz, st, sidx, wc);   // main.rs:204
+                    ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
+                    const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
                     if (!ok && lane == 0) l_ctl[1] = 1u;
-                    const float lnd = fabsf(h[3] * sx + h[4] * sy + h[5] * sz);       // main.rs:207
-                    bool lit = true;                                                  // main.rs:229-231
-                    if (sidx != kNone) {                                              // main.rs:219-227
-                        const float qx = hx - (hx + st * sx), qy = hy - (hy + st * sy), qz = hz - (hz + st * sz);
-                        lit = sqrtf(qx * qx + qy * qy + qz * qz) > dist_light;
-                    }
-                    if (valid) l_res[hp * res_stride + si] = lit ? lnd : kOccluded;
+                    shadow_result(l_hit, l_res, res_stride, sr);
                 }
                 if (COUNT) t_ph2 += wall_clock64() - t_mark;
                 __syncthreads();
 
                 // ------------- phase 3: ordered accumulation, one work-item per pixel (wave 0) -------------
                 if (COUNT) t_mark = wall_clock64();
-                if (wave == 0 && hit) {
-                    const float *res = l_res + slot * res_stride;
-                    for (uint32_t i = 0; i < bc; ++i) {                               // i ascending, main.rs:209-216
-                        const float lnd = res[i];
-                        if (!(lnd < 0.0f)) {
-                            acc_r = acc_r + ((cr * lnd) / denom);
-                            acc_g = acc_g + ((cg * lnd) / denom);
-                            acc_b = acc_b + ((cb * lnd) / denom);
+                if (wave == 0) {
+                    // grey surfaces (every BASELINE scene): the three channel sums are the same f32 sequence
+                    const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && acc_r == acc_g && acc_g == acc_b)) == 0ull;
+                    if (hit) {
+                        const float *res = l_res + slot * res_stride;
+                        if (grey_tile) {
+                            uint32_t i = 0;
+                            for (; i + 4u <= bc; i += 4u) {                           // i ascending, main.rs:209-216
+                                // the four quotients are independent of the running sum; the adds stay in order
+                                const float l0 = res[i], l1 = res[i + 1u], l2 = res[i + 2u], l3 = res[i + 3u];
+                                const float q0 = (cr * l0) / denom, q1 = (cr * l1) / denom, q2 = (cr * l2) / denom,
+                                            q3 = (cr * l3) / denom;
+                                if (!(l0 < 0.0f)) acc_r = acc_r + q0;
+                                if (!(l1 < 0.0f)) acc_r = acc_r + q1;
+                                if (!(l2 < 0.0f)) acc_r = acc_r + q2;
+                                if (!(l3 < 0.0f)) acc_r = acc_r + q3;
+                            }
+                            for (; i < bc; ++i) {
+                                const float lnd = res[i];
+                                if (!(lnd < 0.0f)) acc_r = acc_r + ((cr * lnd) / denom);
+                            }
+                            acc_g = acc_r;
+                            acc_b = acc_r;
+                        } else {
+                            for (uint32_t i = 0; i < bc; ++i) {                       // i ascending, main.rs:209-216
+                                const float lnd = res[i];
+                                if (!(lnd < 0.0f)) {
+                                    acc_r = acc_r + ((cr * lnd) / denom);
+                                    acc_g = acc_g + ((cg * lnd) / denom);
+                                    acc_b = acc_b + ((cb * lnd) / denom);
+                                }
+                            }
                         }
                     }
                 }
@@ -254,27 +317,29 @@ __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD) trace
         if (l_ctl[1] != 0u) {      // some ray was outside the tree-independent regime: reference_tiles_kernel redoes the tile
             primary_hits = 0;      // ... and counts its hits
             if (lane == 0) {
-                redo[1u + atomicAdd(&redo[0], 1u)] = tile_y * gridDim.x + tile_x;
+                queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_y * tiles_x + tile_x;
                 if (COUNT && counters) atomicAdd(&counters[5], 1ull);
             }
         } else if (in_frame) {
             store_pixel(S, out, px, ly, acc_r, acc_g, acc_b);
         }
     }
+    primary_hits_total += primary_hits;
 
-    if (COUNT && lane == 0) {
-        flush_counters<COUNT>(counters, primary_hits, wc);
-        if (wave_prof) {   // diagnostics: per-tile work and residency (rtx_debug_wave_profile); zeroed by the host
-            unsigned long long *p = wave_prof + 8ull * ((unsigned long long)tile_y * gridDim.x + tile_x);
-            atomicAdd(&p[0], wc.node_visits);
-            atomicAdd(&p[1], wc.tri_visits);
-            atomicMax(&p[2], ~t_start);   // stored inverted so that a zeroed buffer works as the identity
-            atomicMax(&p[3], (unsigned long long)wall_clock64());
-            atomicMax(&p[4], t_ph1);      // wave 0: primary rays
-            atomicMax(&p[5], t_ph2);      // slowest wave: shadow rays
-            atomicMax(&p[6], t_ph3);      // wave 0: ordered accumulation
-        }
+    if (COUNT && lane == 0 && wave_prof) {   // diagnostics: per-tile work and residency (rtx_debug_wave_profile); zeroed by the host
+        unsigned long long *p = wave_prof + 8ull * ((unsigned long long)tile_y * tiles_x + tile_x);
+        atomicAdd(&p[0], wc.node_visits - nv0);
+        atomicAdd(&p[1], wc.tri_visits - tv0);
+        atomicMax(&p[2], ~t_start);   // stored inverted so that a zeroed buffer works as the identity
+        atomicMax(&p[3], (unsigned long long)wall_clock64());
+        atomicMax(&p[4], t_ph1);      // wave 0: primary rays
+        atomicMax(&p[5], t_ph2);      // slowest wave: shadow rays
+        atomicMax(&p[6], t_ph3);      // wave 0: ordered accumulation
     }
+    __syncthreads();   // the control words are rewritten by the next tile
+    }   // tile loop
+
+    if (COUNT && lane == 0) flush_counters<COUNT>(counters, primary_hits_total, wc);
 }
 
 // One wavefront per queued tile, one work-item per pixel, the reference's loop order (main.rs:180-240)
@@ -291,11 +356,11 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
     const NodeRec RTX_CONSTANT *stream = (const NodeRec RTX_CONSTANT *)(have_ref ? S.ref_nodes : S.nodes);
     const uint32_t n_stream = have_ref ? S.n_ref_nodes : S.n_nodes;
     const uint32_t lane = threadIdx.x;
-    const uint32_t n_redo = __builtin_amdgcn_readfirstlane(redo[0]);
+    const uint32_t n_redo = __builtin_amdgcn_readfirstlane(redo[kQueueRedoCount]);
     WaveCounters wc;
     unsigned long long primary_hits = 0;
     for (uint32_t q = blockIdx.x; q < n_redo; q += gridDim.x) {
-        const uint32_t tid = __builtin_amdgcn_readfirstlane(redo[1u + q]);
+        const uint32_t tid = __builtin_amdgcn_readfirstlane(redo[kQueueHeader + q]);
         uint32_t px, py, ly;
         const bool in_frame = tile_pixel(S, ts, tid % tiles_x, tid / tiles_x, lane, px, py, ly);
         float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
@@ -355,15 +420,33 @@ hipError_t launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_o
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
     const dim3 block(64 * NW);
-    const dim3 grid((S.width + 7u) / 8u, (ts.local_rows + 7u) / 8u);
-    hipError_t e = hipMemsetAsync(d_redo, 0, sizeof(uint32_t), stream);   // queue length
+    const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    // persistent grid: what the device keeps resident (occupancy query, cached per variant and LDS size), never
+    // more workgroups than tiles; a workgroup that finds the queue empty exits, so over-asking is harmless
+    static thread_local int cached_dev = -1, cached_blocks = 0;
+    static thread_local size_t cached_lds = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, NW>), grid, block, lds_bytes, stream, S, ts, batch, d_out,
-                       d_redo, d_counters, d_wave_prof);
+    if (dev != cached_dev || lds_bytes != cached_lds) {
+        int per_cu = 0, cus = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_shade_kernel<COUNT, FAST, NW>, 64 * NW, lds_bytes);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cached_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+        cached_dev = dev;
+        cached_lds = lds_bytes;
+    }
+    const uint32_t grid = n_tiles < static_cast<uint32_t>(cached_blocks) ? n_tiles : static_cast<uint32_t>(cached_blocks);
+    e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream);   // redo count, next tile
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, NW>), dim3(grid), block, lds_bytes, stream, S, ts, batch, tiles_x,
+                       tiles_y, d_out, d_redo, d_counters, d_wave_prof);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const uint32_t n_tiles = grid.x * grid.y;
     hipLaunchKernelGGL((reference_tiles_kernel<COUNT>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream, S,
-                       ts, grid.x, d_out, d_redo, d_counters);
+                       ts, tiles_x, d_out, d_redo, d_counters);
     return hipGetLastError();
 }
 
@@ -389,7 +472,7 @@ uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant) { return (S.width
 
 size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts)
 {
-    return sizeof(uint32_t) * (1u + static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u));
+    return sizeof(uint32_t) * (kQueueHeader + static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u));
 }
 
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,

@@ -202,89 +202,99 @@ __device__ __forceinline__ void closest_hit_reference(const NodeRec RTX_CONSTANT
     }
 }
 
-// One wave-uniform closest-hit traversal.  `active` lanes carry a ray; the others never vote.
-// best_t / best_idx: minimum accepted distance and the caller-order index of its triangle.
-// Valid for rays whose direction components are all regular (direction_is_regular): then every term of
-// the slab test is finite, the test is monotone in the box, and the result does not depend on the tree.
-// Returns false (and traces nothing) when an active lane's direction is hard: the tile is then re-rendered
-// by reference_tiles_kernel.  A wavefront holding a soft direction uses the exact slab test for this
-// traversal (the multiply-based culling needs finite 1/d).
+// A ray as a lane carries it through a traversal.
+struct LaneRay {
+    float ox, oy, oz;     // origin
+    float dx, dy, dz;     // unit direction (Ray::new)
+    float ix, iy, iz;     // 1/d, used by the multiply-based culling only
+    float best_t;         // minimum accepted distance so far
+    uint32_t best_idx;    // caller-order index of its triangle, kNone = no hit
+    bool active;          // lanes without a ray never vote
+};
+
+__device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    LaneRay r;
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    r.best_t = __builtin_inff();
+    r.best_idx = kNone;
+    r.active = active;
+    return r;
+}
+
+__device__ __forceinline__ bool box_pass(bool use_fast, const NodeRec &n, const LaneRay &r)
+{
+    if (use_fast)
+        return slab_fast(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
+    return slab_exact(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+}
+
+// The triangles of one leaf against the ray of every lane: Triangle::intersect (triangle.rs:66-94), the leaf
+// rule x < 1.0 -> None (bvh.rs:64-67), the leaf's own box (bvh.rs:52, exact arithmetic) and the tie rule.
+template <bool COUNT>
+__device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
+                                               const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
+                                               LaneRay &r, unsigned long long n_active, WaveCounters &wc)
+{
+    for (uint32_t k = 0; k < count; ++k) {
+        const TriRec RTX_CONSTANT *tr = tris + (first + k);
+        const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
+        const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
+        const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
+        if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+        const float pvx = r.dy * e2z - r.dz * e2y;                                   // :69
+        const float pvy = r.dz * e2x - r.dx * e2z;
+        const float pvz = r.dx * e2y - r.dy * e2x;
+        const float det = e1x * pvx + e1y * pvy + e1z * pvz;                         // :70
+        const bool parallel = det < 0.00001f && det > -0.00001f;                     // :73
+        const float inv = 1.0f / det;                                                // :77
+        const float tvx = r.ox - v0x, tvy = r.oy - v0y, tvz = r.oz - v0z;            // :78
+        const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;                   // :79
+        const bool out_u = u < 0.0f || u > 1.0f;                                     // :80
+        const float qvx = tvy * e1z - tvz * e1y;                                     // :84
+        const float qvy = tvz * e1x - tvx * e1z;
+        const float qvz = tvx * e1y - tvy * e1x;
+        const float v = (r.dx * qvx + r.dy * qvy + r.dz * qvz) * inv;                // :85
+        const bool out_v = v < 0.0f || u + v > 1.0f;                                 // :86
+        const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;                   // :92
+        const bool some = !parallel && !out_u && !out_v;
+        if (r.active && some && !(t < 1.0f)) {
+            if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
+                           r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) {
+                const uint32_t idx = tr->idx;
+                bool take = t < r.best_t;
+                if (!take && t == r.best_t && r.best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
+                    take = shade[idx].rank > shade[r.best_idx].rank;
+                if (take) { r.best_t = t; r.best_idx = idx; }
+            }
+        }
+    }
+}
+
+// One wave-uniform closest-hit traversal over the library's stream.
+// Valid for rays whose direction components are regular or soft (see the classes above): then the result
+// does not depend on the tree.  Returns false (and traces nothing) when an active lane's direction is hard:
+// the tile is then re-rendered by reference_tiles_kernel.  A wavefront holding a soft direction uses the
+// exact slab test for this traversal (the multiply-based culling needs finite 1/d).
 template <bool COUNT, bool FAST>
 __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
-                                            bool active, float ox, float oy, float oz,
-                                            float dx, float dy, float dz,
-                                            float &best_t, uint32_t &best_idx, WaveCounters &wc)
+                                            LaneRay &r, WaveCounters &wc)
 {
-    best_t = __builtin_inff();
-    best_idx = kNone;
-    if (__ballot(active && direction_is_hard(dx, dy, dz)) != 0ull) return false;
-    const bool use_fast = FAST && __ballot(active && !direction_is_regular(dx, dy, dz)) == 0ull;
+    if (__ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
+    const bool use_fast = FAST && __ballot(r.active && !direction_is_regular(r.dx, r.dy, r.dz)) == 0ull;
     unsigned long long n_active = 0;
-    if (COUNT) n_active = __popcll(__ballot(active));
-
-    float ix = 0.0f, iy = 0.0f, iz = 0.0f;
-    if (use_fast) {
-        ix = 1.0f / dx;
-        iy = 1.0f / dy;
-        iz = 1.0f / dz;
-    }
-
+    if (COUNT) n_active = __popcll(__ballot(r.active));
     uint32_t i = 0;
     while (i < n_nodes) {
         const NodeRec cur = load_node(nodes + i);
         const bool leaf = (cur.info & kLeafFlag) != 0u;
-        bool pass;
-        if (use_fast)
-            pass = slab_fast(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
-                             ox, oy, oz, ix, iy, iz);
-        else
-            pass = slab_exact(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
-                              ox, oy, oz, dx, dy, dz);
-        const bool any = __ballot(active && pass) != 0ull;
+        const bool any = __ballot(r.active && box_pass(use_fast, cur, r)) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
-
-        if (leaf && any) {
-            const uint32_t first = cur.info & ~kLeafFlag;
-            const uint32_t count = cur.link;
-            for (uint32_t k = 0; k < count; ++k) {
-                const TriRec RTX_CONSTANT *tr = tris + (first + k);
-                const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
-                const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
-                const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
-                if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
-                // Triangle::intersect — triangle.rs:66-94
-                const float pvx = dy * e2z - dz * e2y;                                   // :69
-                const float pvy = dz * e2x - dx * e2z;
-                const float pvz = dx * e2y - dy * e2x;
-                const float det = e1x * pvx + e1y * pvy + e1z * pvz;                     // :70
-                const bool parallel = det < 0.00001f && det > -0.00001f;                 // :73
-                const float inv = 1.0f / det;                                            // :77
-                const float tvx = ox - v0x, tvy = oy - v0y, tvz = oz - v0z;              // :78
-                const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;               // :79
-                const bool out_u = u < 0.0f || u > 1.0f;                                 // :80
-                const float qvx = tvy * e1z - tvz * e1y;                                 // :84
-                const float qvy = tvz * e1x - tvx * e1z;
-                const float qvz = tvx * e1y - tvy * e1x;
-                const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;                  // :85
-                const bool out_v = v < 0.0f || u + v > 1.0f;                             // :86
-                const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;               // :92
-                const bool some = !parallel && !out_u && !out_v;
-                // leaf rule: x < 1.0 -> None (bvh.rs:64-67)
-                if (active && some && !(t < 1.0f)) {
-                    // the leaf's own box gates the triangle test in the reference (bvh.rs:52): exact arithmetic
-                    if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
-                                   ox, oy, oz, dx, dy, dz)) {
-                        const uint32_t idx = tr->idx;
-                        bool take = t < best_t;
-                        if (!take && t == best_t && best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
-                            take = shade[idx].rank > shade[best_idx].rank;
-                        if (take) { best_t = t; best_idx = idx; }
-                    }
-                }
-            }
-        }
+        if (leaf && any) leaf_triangles<COUNT>(tris, shade, cur.info & ~kLeafFlag, cur.link, r, n_active, wc);
         // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
         i = (any || leaf) ? i + 1u : cur.link;
     }
