@@ -40,6 +40,11 @@ WORKLOADS = {
     "c3": dict(desc="configs[2]: big_bunny.obj 1920x1080", objs=["big_bunny.obj"], width=1920, height=1080),
     "c4": dict(desc="configs[3]: big_bunny.obj 4096x4096", objs=["big_bunny.obj"], width=4096, height=4096),
     "c1b": dict(desc="big_bunny.obj 256x256 (test size)", objs=["big_bunny.obj"], width=256, height=256),
+    # configs[4]; no cpu_baseline: the reference's O(n^2) BVH build is infeasible at 10^6 primitives
+    "c5": dict(desc="configs[4]: synthetic 1M-triangle random mesh 4096x4096", objs=[], synthetic=1000000,
+               width=4096, height=4096),
+    "c5s": dict(desc="synthetic 100k-triangle random mesh 1024x1024 (reduced configs[4])", objs=[], synthetic=100000,
+                width=1024, height=1024),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak (counts an FMA as 2 flop)
@@ -133,7 +138,13 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
     samples = rtx.gen_samples()
-    scene = rtx.default_scene([os.path.join(ROOT, "models", o) for o in wl["objs"]], W, H, samples)
+    if wl.get("synthetic"):
+        tris, rgb = rtx.synthetic_primitives(wl["synthetic"])
+        scene = rtx.Scene(W, H, tris, rgb, samples)
+        asset = "synthetic mesh (splitmix64 seed %d)" % rtx.SYNTHETIC_SEED
+    else:
+        scene = rtx.default_scene([os.path.join(ROOT, "models", o) for o in wl["objs"]], W, H, samples)
+        asset = "reference asset models/%s" % wl["objs"][0]
     info = scene.info()
     scene.upload(local_rank)                               # inputs resident in HBM before timing
 
@@ -201,8 +212,7 @@ def main():
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32",
-            "data": "reference asset models/%s + seeded sample table (splitmix64 seed %d); no dataset download"
-                    % (wl["objs"][0], rtx.DEFAULT_SEED),
+            "data": "%s + seeded sample table (splitmix64 seed %d); no dataset download" % (asset, rtx.DEFAULT_SEED),
             "config": {"workload": wl["desc"] + ", 1 spp, 100 light samples, default scene of src/main.rs:327-358",
                        "width": W, "height": H, "n_tris": info["n_tris"], "tile_rows": tile_rows,
                        "partition": "row tiles, tile t -> rank t %% %d, no collective" % world,
@@ -214,9 +224,10 @@ def main():
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "trace_shade_kernel", "kernel_ms": round(kernel_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "scene is L2-resident (%.2f MB): the kernel is FP32-VALU bound, see roofline_valu; "
-                                 "survey_b_alg_* = SURVEY 8(d) brute-force-equivalent bytes"
+                         "note": "scene records %.2f MB (L2-resident when < 4 MB): the kernel is FP32-VALU / latency bound, "
+                                 "see roofline_valu; survey_b_alg_* = SURVEY 8(d) brute-force-equivalent bytes"
                                  % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),
+                         "redo_tiles": c[5],
                          "survey_b_alg_bytes": int(b_alg_brute),
                          "survey_b_alg_frac": round(b_alg_brute / world / kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline_valu": {"bound": "fp32-valu", "achieved": round(ach_tf, 3), "peak": VALU_PEAK_TFLOPS,
@@ -224,7 +235,7 @@ def main():
                               "box_tests": box_tests, "tri_tests": tri_tests,
                               "wave_node_visits": node_visits, "wave_tri_visits": tri_visits},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not wl.get("synthetic"):
             line["cpu_baseline"] = cpu_baseline(wl, samples, args.cpu_seconds, args.cpu_threads)
             line["cpu_baseline"]["gpu_over_cpu"] = round(mrays / line["cpu_baseline"]["value"], 1)
         else:

@@ -206,6 +206,11 @@ int  rtxh_ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank
 void rtxh_gen_samples(uint64_t seed, uint32_t n_pairs, float *out);
 /* RGB8 PNG (what img.save(.., image::PNG) produces on decode, src/main.rs:313-315) */
 int  rtxh_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+/* BASELINE.json configs[4], "synthetic 1M-triangle random mesh": n_tris triangles whose centroid is uniform in
+ * the big_bunny AABB [-92.4,59.7]x[32.7,183.4]x[-60.5,57.6] and whose vertices are centroid + uniform offsets
+ * in [-1,1]^3; draws from splitmix64(seed) as in rtxh_gen_samples, 12 per triangle
+ * (centroid xyz, then v0 xyz, v1 xyz, v2 xyz); zero-area triangles are redrawn.  out: n_tris x 9. */
+int  rtxh_synthetic_mesh(uint64_t seed, uint32_t n_tris, float *out_v0v1v2);
 
 #ifdef __cplusplus
 }

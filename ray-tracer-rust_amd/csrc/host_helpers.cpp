@@ -156,6 +156,40 @@ void rtxh_gen_samples(uint64_t seed, uint32_t n_pairs, float *out)
     }
 }
 
+// Synthetic soup of BASELINE.json configs[4] (see include/rtx.h).  f32 arithmetic, one rounding per operation:
+// c = lo + f*(hi-lo) per axis, vertex = c + (2f-1).
+int rtxh_synthetic_mesh(uint64_t seed, uint32_t n_tris, float *out)
+{
+    if (!out) return RTX_ERR_BAD_ARG;
+    static const float lo[3] = {-92.4f, 32.7f, -60.5f}, hi[3] = {59.7f, 183.4f, 57.6f};
+    uint64_t state = seed;
+    auto draw = [&state]() {
+        state += 0x9E3779B97F4A7C15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return static_cast<float>(static_cast<uint32_t>(z >> 40)) * (1.0f / 16777216.0f);
+    };
+    for (uint32_t i = 0; i < n_tris;) {
+        float c[3], v[9];
+        for (int k = 0; k < 3; ++k) {
+            const float span = hi[k] - lo[k];
+            c[k] = lo[k] + draw() * span;
+        }
+        for (int k = 0; k < 9; ++k) {
+            const float off = 2.0f * draw() - 1.0f;
+            v[k] = c[k % 3] + off;
+        }
+        const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+        const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+        if (nx == 0.0f && ny == 0.0f && nz == 0.0f) continue;   // zero area: draw this triangle again
+        std::memcpy(out + 9 * static_cast<size_t>(i), v, sizeof v);
+        ++i;
+    }
+    return RTX_OK;
+}
+
 int rtxh_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb)
 {
     if (!path || !rgb || !width || !height) return RTX_ERR_BAD_ARG;

@@ -107,6 +107,7 @@ _SIGS = {
     "rtxh_ref_leaf_rank": (C.c_int, [C.c_uint32, f32p, u32p]),
     "rtxh_gen_samples": (None, [C.c_uint64, C.c_uint32, f32p]),
     "rtxh_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rtxh_synthetic_mesh": (C.c_int, [C.c_uint64, C.c_uint32, f32p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(_lib, _name)
@@ -181,6 +182,25 @@ def write_png(path, img):
     h, w, c = img.shape
     assert c == 3
     _check(_lib.rtxh_write_png(os.fsencode(path), w, h, img.ctypes.data), "rtxh_write_png")
+
+
+SYNTHETIC_SEED = 12345
+
+
+def synthetic_mesh(n_tris, seed=SYNTHETIC_SEED):
+    """BASELINE.json configs[4]: random triangle soup in the big_bunny AABB -> float32 [n, 9]."""
+    out = np.empty((n_tris, 9), dtype=np.float32)
+    _check(_lib.rtxh_synthetic_mesh(seed, n_tris, _fp(out)), "rtxh_synthetic_mesh")
+    return out
+
+
+def synthetic_primitives(n_tris, seed=SYNTHETIC_SEED):
+    """Synthetic soup (colour 1,1,1) + the ground, ground last as in main() (src/main.rs:335)."""
+    t = synthetic_mesh(n_tris, seed)
+    tris = np.concatenate([t, np.asarray(GROUND_TRI, np.float32).reshape(1, 9)])
+    rgb = np.concatenate([np.tile(np.asarray(MESH_RGB, np.float32), (n_tris, 1)),
+                          np.asarray(GROUND_RGB, np.float32).reshape(1, 3)])
+    return np.ascontiguousarray(tris), np.ascontiguousarray(rgb)
 
 
 def default_primitives(obj_paths):

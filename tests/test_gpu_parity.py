@@ -252,3 +252,32 @@ def test_random_soups_including_degenerate_rays(rtx, orc, samples_seeded, sample
     assert st["primary_hits"] == ost["primary_hits"]
     nz = assert_image_close(img, ref, "soup seed %d" % seed)
     assert nz == 0
+
+
+def test_synthetic_soup_with_reference_tree(rtx, orc, samples_seeded):
+    """BASELINE configs[4] at test size: 20,000-triangle random soup in the big_bunny AABB + ground.  Small enough for
+    the reference's O(n^2) tree, so the oracle's faithful BVH is the checker and the library builds the same tree."""
+    W = H = 64
+    tris, rgb = rtx.synthetic_primitives(20000)
+    ref, ost = orc.Scene(W, H, tris, rgb, samples_seeded, nb_light_sample=24).render_rows(mode=orc.MODE_BVH)
+    with rtx.Scene(W, H, tris, rgb, samples_seeded, nb_light_sample=24) as s:
+        assert s.info()["n_ref_nodes"] == 2 * len(tris) - 1
+        img, st = s.render_rows(stats=True)
+    assert st["primary_hits"] == ost["primary_hits"] and st["redo_tiles"] == 0
+    assert assert_image_close(img, ref, "synthetic 20k") == 0
+
+
+def test_synthetic_soup_beyond_reference_tree(rtx, orc, samples_seeded):
+    """60,001 primitives: past RTX_REFTREE_AUTO's limit, no reference tree (the reference could not build one in
+    reasonable time either).  Checker: the oracle's leaf-gated brute force, which equals the faithful BVH for
+    every ray without a -0.0 direction component; exact ties would be the only other
+    difference and are asserted absent."""
+    W = H = 32
+    tris, rgb = rtx.synthetic_primitives(60000)
+    osc = orc.Scene(W, H, tris, rgb, samples_seeded, nb_light_sample=8, build_bvh=False)
+    ref, ost = osc.render_rows(mode=orc.MODE_LEAFBOX)
+    with rtx.Scene(W, H, tris, rgb, samples_seeded, nb_light_sample=8) as s:
+        assert s.info()["n_ref_nodes"] == 0
+        img, st = s.render_rows(stats=True)
+    assert st["primary_hits"] == ost["primary_hits"] and st["redo_tiles"] == 0
+    assert assert_image_close(img, ref, "synthetic 60k") == 0

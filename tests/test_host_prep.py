@@ -274,3 +274,32 @@ def test_reference_tree_stream(rtx, orc, samples_half):
         assert s.info()["n_ref_nodes"] == 0 and len(s.ref_nodes()) == 0
     with rtx.Scene(32, 32, tris[:50], rgb[:50], samples_half[:64], tie_rank=None) as s:
         assert s.info()["n_ref_nodes"] == 0          # tie_rank=None: index order, no reference tree
+
+
+def test_synthetic_mesh_generator(rtx):
+    """rtxh_synthetic_mesh against an independent numpy evaluation of the same recipe (SURVEY 8(d), configs[4])."""
+    def splitmix_f32(seed, n):
+        M = (1 << 64) - 1
+        out, s = np.empty(n, np.float32), seed
+        for i in range(n):
+            s = (s + 0x9E3779B97F4A7C15) & M
+            z = s
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            z ^= z >> 31
+            out[i] = np.float32(z >> 40) * np.float32(1.0 / 16777216.0)
+        return out
+    F = np.float32
+    n = 400
+    f = splitmix_f32(rtx.SYNTHETIC_SEED, 12 * n).reshape(n, 12)
+    lo, hi = np.array([-92.4, 32.7, -60.5], F), np.array([59.7, 183.4, 57.6], F)
+    c = lo + f[:, 0:3] * (hi - lo)
+    v = np.tile(c, (1, 3)) + (F(2.0) * f[:, 3:12] - F(1.0))
+    t = rtx.synthetic_mesh(n)
+    assert np.array_equal(t, v.astype(F))
+    assert (t.reshape(n, 3, 3).min(axis=(0, 1)) >= lo - 1).all() and (t.reshape(n, 3, 3).max(axis=(0, 1)) <= hi + 1).all()
+    tris, rgb = rtx.synthetic_primitives(20000)
+    assert tris.shape == (20001, 9) and tris[-1].tolist() == list(rtx.GROUND_TRI) and rgb[-1].tolist() == [0.5, 0.5, 0.5]
+    with rtx.Scene(16, 16, tris, rgb, rtx.gen_samples(n_pairs=64), tie_rank=None) as s:
+        nodes, order = s.nodes()
+        _check_stream(nodes, order, tris, len(tris))
