@@ -43,6 +43,8 @@ struct DeviceState {
     unsigned long long *d_counters = nullptr;
     uint32_t *d_redo = nullptr;   // queue of tiles for reference_tiles_kernel
     size_t d_redo_cap = 0;
+    rtx::StreamWorkspace ws{};    // streamed pipeline: intermediate products in HBM
+    rtx::StreamWorkspaceBytes ws_cap{};
     uint8_t *h_stage = nullptr;   // pinned
     size_t h_stage_cap = 0;
 };
@@ -108,7 +110,7 @@ uint32_t kernel_variant()
 {
     static const uint32_t v = [] {
         const char *e = std::getenv("RTX_VARIANT");
-        return e ? static_cast<uint32_t>(std::atoi(e)) & 7u : rtx::kDefaultVariant;
+        return e ? static_cast<uint32_t>(std::atoi(e)) & rtx::kVariantMask : rtx::kDefaultVariant;
     }();
     return v;
 }
@@ -192,6 +194,36 @@ int ensure_redo(DeviceState &st, size_t bytes)
     return RTX_OK;
 }
 
+template <class T>
+int grow_buffer(T **ptr, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes) return RTX_OK;
+    if (*ptr) RTX_HIP(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    RTX_HIP(hipMalloc(reinterpret_cast<void **>(ptr), bytes));
+    *cap = bytes;
+    return RTX_OK;
+}
+
+// workspace of the streamed pipeline for a launch; NULL result when the variant does not use it
+int ensure_stream_ws(DeviceState &st, const rtx::DeviceScene &S, const rtx::TileSpec &ts, const rtx::StreamWorkspace **out)
+{
+    *out = nullptr;
+    if (!(kernel_variant() & rtx::kVariantStream)) return RTX_OK;
+    const rtx::StreamWorkspaceBytes need = rtx::stream_workspace_bytes(S, ts);
+    int rc;
+    if ((rc = grow_buffer(&st.ws.hits, &st.ws_cap.hits, need.hits)) != RTX_OK) return rc;
+    if ((rc = grow_buffer(&st.ws.pix_slot, &st.ws_cap.pix_slot, need.pix_slot)) != RTX_OK) return rc;
+    if ((rc = grow_buffer(&st.ws.tiles, &st.ws_cap.tiles, need.tiles)) != RTX_OK) return rc;
+    if ((rc = grow_buffer(&st.ws.chunks, &st.ws_cap.chunks, need.chunks)) != RTX_OK) return rc;
+    if ((rc = grow_buffer(&st.ws.results, &st.ws_cap.results, need.results)) != RTX_OK) return rc;
+    if (need.acc && (rc = grow_buffer(&st.ws.acc, &st.ws_cap.acc, need.acc)) != RTX_OK) return rc;
+    if ((rc = grow_buffer(&st.ws.ctr, &st.ws_cap.ctr, need.ctr)) != RTX_OK) return rc;
+    *out = &st.ws;
+    return RTX_OK;
+}
+
 uint32_t tiles_rows(uint32_t height, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows)
 {
     if (!tile_rows || !tile_stride) return 0;
@@ -229,10 +261,12 @@ int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool co
     if ((rc = ensure_out(st, bytes ? bytes : 16, stage)) != RTX_OK) return rc;
     const rtx::DeviceScene S = device_scene(scene, st);
     if ((rc = ensure_redo(st, rtx::trace_redo_bytes(S, ts))) != RTX_OK) return rc;
+    const rtx::StreamWorkspace *ws = nullptr;
+    if ((rc = ensure_stream_ws(st, S, ts, &ws)) != RTX_OK) return rc;
     if (count)
         RTX_HIP(hipMemsetAsync(st.d_counters, 0, rtx::kNumCounters * sizeof(unsigned long long), st.stream));
     RTX_HIP(hipEventRecord(st.ev0, st.stream));
-    RTX_HIP(rtx::launch_trace_shade(S, ts, st.d_out, st.d_redo, count ? st.d_counters : nullptr, nullptr,
+    RTX_HIP(rtx::launch_trace_shade(S, ts, st.d_out, st.d_redo, ws, count ? st.d_counters : nullptr, nullptr,
                                     kernel_variant(), st.stream));
     RTX_HIP(hipEventRecord(st.ev1, st.stream));
     return RTX_OK;
@@ -288,7 +322,8 @@ void rtx_scene_destroy(RtxScene *scene)
         DeviceGuard g(kv.first);
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
-        void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters, st.d_redo};
+        void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters, st.d_redo,
+                        st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);
         if (st.ev0) (void)hipEventDestroy(st.ev0);
@@ -453,7 +488,9 @@ int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, ui
     const rtx::DeviceScene S = device_scene(scene, *st);
     // the redo queue is library-owned per device: launches on one device must be ordered on one stream
     if ((rc = ensure_redo(*st, rtx::trace_redo_bytes(S, ts))) != RTX_OK) return rc;
-    RTX_HIP(rtx::launch_trace_shade(S, ts, static_cast<uint8_t *>(d_out_rgb), st->d_redo,
+    const rtx::StreamWorkspace *ws = nullptr;
+    if ((rc = ensure_stream_ws(*st, S, ts, &ws)) != RTX_OK) return rc;
+    RTX_HIP(rtx::launch_trace_shade(S, ts, static_cast<uint8_t *>(d_out_rgb), st->d_redo, ws,
                                     reinterpret_cast<unsigned long long *>(d_counters), nullptr, kernel_variant(),
                                     static_cast<hipStream_t>(stream)));
     return RTX_OK;
@@ -486,7 +523,7 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     const rtx::TileSpec ts{row0, nrows, nrows, nrows};
     if (ensure_redo(*st, rtx::trace_redo_bytes(S, ts)) != RTX_OK) { (void)hipFree(d_prof); return RTX_ERR_OOM; }
     if (e == hipSuccess)
-        e = rtx::launch_trace_shade(S, ts, st->d_out, st->d_redo, nullptr, d_prof, kernel_variant(), st->stream);
+        e = rtx::launch_trace_shade(S, ts, st->d_out, st->d_redo, nullptr, nullptr, d_prof, kernel_variant(), st->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_prof, prof_bytes, hipMemcpyDeviceToHost, st->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(st->stream);
     (void)hipFree(d_prof);

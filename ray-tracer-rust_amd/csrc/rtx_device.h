@@ -36,6 +36,31 @@ struct TileSpec {
     uint32_t local_rows;
 };
 
+// Device workspace of the streamed pipeline (primary_kernel / shadow_kernel / accumulate_kernel): the
+// intermediate products that the fused kernel keeps in LDS live in HBM here.  Sized for the pixels of one
+// launch (tiles x 64), grow-only, owned by the library per device.
+struct TileDesc {
+    uint32_t first;      // first hit record / result row block of the tile
+    uint32_t n_hit;
+    uint32_t flags;      // bit 0: number the tile's rays sample-major; bit 1: queued for the reference re-render
+    uint32_t pad;
+};
+struct HitRec {          // 48 B
+    float p[3], n[3], rgb[3], pad[3];
+};
+static_assert(sizeof(TileDesc) == 16 && sizeof(HitRec) == 48, "stream record sizes");
+struct StreamWorkspace {
+    HitRec   *hits;      // one per primary hit, compacted per tile
+    uint32_t *pix_slot;  // tiles x 64: hit record of the pixel, or 0xFFFFFFFF
+    TileDesc *tiles;     // one per tile
+    uint2    *chunks;    // one per 64 shadow rays: (tile, chunk within the tile)
+    float    *results;   // hits x nb_light: |n.l| or the "occluded" marker, per tile [sample][hit pixel]
+    float    *acc;       // tiles x 64 x 3 running sums, only when nb_ray > 1
+    uint32_t *ctr;       // hit count, chunk count, chunk cursor
+};
+struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr; };
+StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts);
+
 // counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits
 constexpr int kNumCounters = 8;
 
@@ -44,7 +69,10 @@ constexpr uint32_t kMaxLightBatch = 128u;
 
 // Kernel variants, kept selectable (RTX_VARIANT) so that profiles can show what each choice is worth:
 // bit 0 = conservative multiply-based box test for inner nodes (else the exact division-based one);
-// bits 1-2 = wavefronts per workgroup: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1.
+// bits 1-2 = wavefronts per workgroup of the fused kernel: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1;
+// bit 3 = streamed pipeline (three kernels, results through HBM) instead of the fused kernel.
+constexpr uint32_t kVariantStream = 8u;
+constexpr uint32_t kVariantMask = 15u;
 constexpr uint32_t kDefaultVariant = 3u;
 
 // d_wave_prof: NULL or kWaveProfWords uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end, primary
@@ -57,8 +85,9 @@ uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
 // [kQueueHeader]; trace_redo_bytes() is its size for a launch.  Reset and consumed inside the launch.
 constexpr uint32_t kQueueRedoCount = 0u, kQueueNextTile = 1u, kQueueHeader = 4u;
 size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts);
+// ws: workspace of the streamed pipeline (may be NULL: the fused kernel is used then)
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
-                              unsigned long long *d_counters, unsigned long long *d_wave_prof,
-                              uint32_t variant, hipStream_t stream);
+                              const StreamWorkspace *ws, unsigned long long *d_counters,
+                              unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream);
 
 }  // namespace rtx

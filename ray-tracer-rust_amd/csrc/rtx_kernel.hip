@@ -411,7 +411,197 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
     if (COUNT && lane == 0) flush_counters<COUNT>(counters, primary_hits, wc);
 }
 
+// =====================================================================================================
+// Streamed form of the same three phases: one kernel each, the frame's shadow rays as ONE flat list of
+// 64-ray chunks pulled by persistent wavefronts.  No workgroup barrier, no LDS, no idle wavefronts while
+// wave 0 traces primaries or adds samples, and the unit of scheduling is one traversal, so a heavy tile
+// cannot hold the frame's tail.  The per-sample results go through HBM instead of LDS: hits x nb_light x
+// 4 B written once and read once (C3: 0.41 GB, C4: 3.3 GB per frame — 288 GB of HBM is what makes this the
+// cheap choice).  Same arithmetic, same order of additions, same bytes.
+//
+//   primary_kernel     one wavefront per 8x8 tile: primary hits, compacted hit records, tile descriptor,
+//                      one chunk descriptor per 64 shadow rays of the tile
+//   shadow_kernel      persistent wavefronts: chunk -> 64 (hit pixel, sample) rays -> |n.l| or "occluded"
+//   accumulate_kernel  one wavefront per tile: ordered sum per pixel, quantise, store
+enum : uint32_t { kCtrHits = 0, kCtrChunks = 1, kCtrCursor = 2, kStreamCtrWords = 4 };
+
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(64) primary_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t r,
+                                                     StreamWorkspace W, uint32_t *__restrict__ queue,
+                                                     unsigned long long *__restrict__ counters)
+{
+    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile_id = blockIdx.x;
+    uint32_t px, py, ly;
+    const bool in_frame = tile_pixel(S, ts, tile_id % tiles_x, tile_id / tiles_x, lane, px, py, ly);
+    WaveCounters wc;
+    float dx, dy, dz;
+    primary_ray(S, in_frame, px, py, r, dx, dy, dz);
+    LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
+    const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
+    const bool hit = ok && in_frame && pr.best_idx != kNone;
+    const unsigned long long hit_mask = __ballot(hit);
+    const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
+    const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));
+    uint32_t first = 0, chunk_base = 0;
+    const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
+    if (lane == 0 && n_hit) {
+        first = atomicAdd(&W.ctr[kCtrHits], n_hit);
+        chunk_base = atomicAdd(&W.ctr[kCtrChunks], n_chunks);
+    }
+    first = __builtin_amdgcn_readfirstlane(first);
+    chunk_base = __builtin_amdgcn_readfirstlane(chunk_base);
+    const uint32_t first_idx = __builtin_amdgcn_readfirstlane(hit_mask ? __shfl(pr.best_idx, __ffsll((long long)hit_mask) - 1) : 0u);
+    const bool one_surface = __ballot(hit && pr.best_idx != first_idx) == 0ull;
+    uint32_t flags = (kOneSurfaceSampleMajor && one_surface) ? 1u : 0u;
+    if (!ok) {   // a hard primary direction: the whole tile goes to the reference re-render
+        flags |= 2u;
+        if (lane == 0) {
+            queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_id;
+            if (COUNT && counters) atomicAdd(&counters[5], 1ull);
+        }
+    }
+    if (hit) {
+        const ShadeRec sh = S.shade[pr.best_idx];
+        HitRec h;
+        h.p[0] = S.eye[0] + pr.best_t * dx;                                          // p_hit, bvh.rs:69
+        h.p[1] = S.eye[1] + pr.best_t * dy;
+        h.p[2] = S.eye[2] + pr.best_t * dz;
+        h.n[0] = sh.normal[0]; h.n[1] = sh.normal[1]; h.n[2] = sh.normal[2];         // main.rs:206
+        h.rgb[0] = sh.rgb[0]; h.rgb[1] = sh.rgb[1]; h.rgb[2] = sh.rgb[2];            // main.rs:191
+        h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
+        W.hits[first + slot] = h;
+    }
+    W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? first + slot : kNone;
+    if (lane == 0) W.tiles[tile_id] = TileDesc{first, n_hit, flags, 0u};
+    for (uint32_t j = lane; j < n_chunks; j += 64u) W.chunks[chunk_base + j] = make_uint2(tile_id, j);
+    if (COUNT && lane == 0) flush_counters<COUNT>(counters, (flags & 2u) ? 0ull : (unsigned long long)n_hit, wc);
+}
+
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(256, COUNT ? 1 : RTX_WAVES_PER_SIMD) shadow_kernel(DeviceScene S, uint32_t r, StreamWorkspace W,
+                                                                                      uint32_t *__restrict__ queue,
+                                                                                      unsigned long long *__restrict__ counters)
+{
+    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = W.ctr[kCtrChunks];
+    WaveCounters wc;
+    // Chunks are dealt round-robin over the resident wavefronts: a tile's chunks are consecutive, so a heavy tile is
+    // spread over many wavefronts.  (A shared cursor — one atomic per chunk — was measured first: a single word
+    // serves ~88 increments per microsecond, 1.65 M chunks took 19 ms of a frame whose traversal needs 3.)
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t c = __builtin_amdgcn_readfirstlane(wave_id); c < n_chunks; c += n_waves) {
+        const uint2 cd = W.chunks[c];
+        const TileDesc td = W.tiles[cd.x];
+        const uint32_t total = td.n_hit * S.nb_light;
+        const bool sample_major = (td.flags & 1u) != 0u;
+        const uint32_t div = sample_major ? td.n_hit : S.nb_light;
+        const uint32_t ray = cd.y * 64u + lane;
+        const bool valid = ray < total;
+        const uint32_t quo = valid ? ray / div : 0u;
+        const uint32_t rem = valid ? ray - quo * div : 0u;
+        const uint32_t hp = sample_major ? rem : quo;
+        const uint32_t si = sample_major ? quo : rem;
+        const HitRec *h = W.hits + (td.first + hp);
+        const float hx = h->p[0], hy = h->p[1], hz = h->p[2];
+        const float *lp = S.light_points + 3u * (r * S.nb_light + si);               // main.rs:194-196 (hoisted)
+        const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;               // p - orig
+        const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                 // main.rs:202
+        LaneRay sr = make_ray(valid, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);   // main.rs:201
+        const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, sr, wc);   // main.rs:204
+        if (!ok) {   // a hard direction in this chunk: queue the tile once for the reference re-render
+            if (lane == 0 && (atomicOr(&W.tiles[cd.x].flags, 2u) & 2u) == 0u) {
+                queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = cd.x;
+                if (COUNT && counters) atomicAdd(&counters[5], 1ull);
+            }
+            continue;
+        }
+        const float lnd = fabsf(h->n[0] * sr.dx + h->n[1] * sr.dy + h->n[2] * sr.dz);   // main.rs:207
+        bool lit = true;                                                              // main.rs:229-231
+        if (sr.best_idx != kNone) {                                                   // main.rs:219-227
+            const float qx = hx - (hx + sr.best_t * sr.dx), qy = hy - (hy + sr.best_t * sr.dy),
+                        qz = hz - (hz + sr.best_t * sr.dz);
+            lit = sqrtf(qx * qx + qy * qy + qz * qz) > dist_light;
+        }
+        // results of a tile: [sample][hit pixel] behind the tile's first row: accumulate_kernel reads it coalesced
+        if (valid) W.results[(size_t)td.first * S.nb_light + (size_t)si * td.n_hit + hp] = lit ? lnd : kOccluded;
+    }
+    if (COUNT && lane == 0) flush_counters<COUNT>(counters, 0ull, wc);
+}
+
+__global__ void __launch_bounds__(64) accumulate_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t r,
+                                                        StreamWorkspace W, uint8_t *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile_id = blockIdx.x;
+    uint32_t px, py, ly;
+    const bool in_frame = tile_pixel(S, ts, tile_id % tiles_x, tile_id / tiles_x, lane, px, py, ly);
+    const TileDesc td = W.tiles[tile_id];
+    const uint32_t slot = W.pix_slot[(size_t)tile_id * 64u + lane];
+    const bool hit = slot != kNone;
+    const size_t pix = (size_t)tile_id * 64u + lane;
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;                                  // main.rs:182
+    if (r != 0u) { acc_r = W.acc[3u * pix]; acc_g = W.acc[3u * pix + 1u]; acc_b = W.acc[3u * pix + 2u]; }
+    if (hit) {
+        const HitRec *h = W.hits + slot;
+        const float cr = h->rgb[0], cg = h->rgb[1], cb = h->rgb[2];
+        const float denom = (float)(S.nb_ray * S.nb_light);                          // main.rs:211
+        const float *res = W.results + (size_t)td.first * S.nb_light + (slot - td.first);
+        for (uint32_t i = 0; i < S.nb_light; ++i) {                                  // i ascending, main.rs:209-216
+            const float lnd = res[(size_t)i * td.n_hit];
+            if (!(lnd < 0.0f)) {
+                acc_r = acc_r + ((cr * lnd) / denom);
+                acc_g = acc_g + ((cg * lnd) / denom);
+                acc_b = acc_b + ((cb * lnd) / denom);
+            }
+        }
+    }
+    if (r + 1u < S.nb_ray) {
+        W.acc[3u * pix] = acc_r; W.acc[3u * pix + 1u] = acc_g; W.acc[3u * pix + 2u] = acc_b;
+    } else if (in_frame) {
+        store_pixel(S, out, px, ly, acc_r, acc_g, acc_b);
+    }
+}
+
 namespace {
+
+template <bool COUNT, bool FAST>
+hipError_t launch_stream(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
+                         const StreamWorkspace &W, unsigned long long *d_counters, hipStream_t stream)
+{
+    const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    static thread_local int cached_dev = -1, cached_blocks = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != cached_dev) {
+        int per_cu = 0, cus = 0;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shadow_kernel<COUNT, FAST>, 256, 0)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        cached_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+        cached_dev = dev;
+    }
+    if ((e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
+        if ((e = hipMemsetAsync(W.ctr, 0, kStreamCtrWords * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL((primary_kernel<COUNT, FAST>), dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, r, W, d_redo,
+                           d_counters);
+        if (S.nb_light)
+            hipLaunchKernelGGL((shadow_kernel<COUNT, FAST>), dim3(cached_blocks), dim3(256), 0, stream, S, r, W, d_redo,
+                               d_counters);
+        hipLaunchKernelGGL(accumulate_kernel, dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, r, W, d_out);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((reference_tiles_kernel<COUNT>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream, S,
+                       ts, tiles_x, d_out, d_redo, d_counters);
+    return hipGetLastError();
+}
 
 template <bool COUNT, bool FAST, int NW>
 hipError_t launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
@@ -475,11 +665,33 @@ size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts)
     return sizeof(uint32_t) * (kQueueHeader + static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u));
 }
 
+StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts)
+{
+    const size_t tiles = static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u);
+    const size_t pixels = tiles * 64u;
+    StreamWorkspaceBytes b;
+    b.hits = pixels * sizeof(HitRec);
+    b.pix_slot = pixels * sizeof(uint32_t);
+    b.tiles = tiles * sizeof(TileDesc);
+    b.chunks = (pixels * S.nb_light / 64u + tiles + 1u) * sizeof(uint2);
+    b.results = pixels * (S.nb_light ? S.nb_light : 1u) * sizeof(float);
+    b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
+    b.ctr = kStreamCtrWords * sizeof(uint32_t);
+    return b;
+}
+
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
-                              unsigned long long *d_counters, unsigned long long *d_wave_prof,
-                              uint32_t variant, hipStream_t stream)
+                              const StreamWorkspace *ws, unsigned long long *d_counters,
+                              unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream)
 {
     if (ts.local_rows == 0) return hipSuccess;
+    if ((variant & kVariantStream) && ws && !d_wave_prof) {
+        if (d_counters)
+            return (variant & 1u) ? launch_stream<true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                                  : launch_stream<true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+        return (variant & 1u) ? launch_stream<false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                              : launch_stream<false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+    }
     if (d_counters || d_wave_prof)
         return launch_select<true>(variant, S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
     return launch_select<false>(variant, S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
