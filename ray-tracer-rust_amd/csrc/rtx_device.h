@@ -71,8 +71,10 @@ constexpr uint32_t kMaxLightBatch = 128u;
 // bit 0 = conservative multiply-based box test for inner nodes (else the exact division-based one);
 // bits 1-2 = wavefronts per workgroup of the fused kernel: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1;
 // bit 3 = streamed pipeline (three kernels, results through HBM) instead of the fused kernel.
+// bit 4 (with bit 3) = two rays per lane in the shadow kernel, packed f32 arithmetic.
 constexpr uint32_t kVariantStream = 8u;
-constexpr uint32_t kVariantMask = 15u;
+constexpr uint32_t kVariantPacked = 16u;
+constexpr uint32_t kVariantMask = 31u;
 constexpr uint32_t kDefaultVariant = 3u;
 
 // d_wave_prof: NULL or kWaveProfWords uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end, primary

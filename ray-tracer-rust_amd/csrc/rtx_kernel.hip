@@ -43,6 +43,9 @@ constexpr bool kOneSurfaceSampleMajor = RTX_ONE_SURFACE_SAMPLE_MAJOR != 0;
 #ifndef RTX_WAVES_PER_SIMD
 #define RTX_WAVES_PER_SIMD 8
 #endif
+#ifndef RTX_PACKED_WAVES_PER_SIMD
+#define RTX_PACKED_WAVES_PER_SIMD 4
+#endif
 
 // byte of a linear channel: number of thresholds (b >= 1) that are <= x  (color.rs:28-33)
 __device__ __forceinline__ uint32_t quantise(const float *__restrict__ thr, float x)
@@ -427,7 +430,8 @@ enum : uint32_t { kCtrHits = 0, kCtrChunks = 1, kCtrCursor = 2, kStreamCtrWords 
 
 template <bool COUNT, bool FAST>
 __global__ void __launch_bounds__(64) primary_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t r,
-                                                     StreamWorkspace W, uint32_t *__restrict__ queue,
+                                                     uint32_t rays_per_chunk, StreamWorkspace W,
+                                                     uint32_t *__restrict__ queue,
                                                      unsigned long long *__restrict__ counters)
 {
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
@@ -446,7 +450,7 @@ __global__ void __launch_bounds__(64) primary_kernel(DeviceScene S, TileSpec ts,
     const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
     const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));
     uint32_t first = 0, chunk_base = 0;
-    const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
+    const uint32_t n_chunks = (n_hit * S.nb_light + rays_per_chunk - 1u) / rays_per_chunk;
     if (lane == 0 && n_hit) {
         first = atomicAdd(&W.ctr[kCtrHits], n_hit);
         chunk_base = atomicAdd(&W.ctr[kCtrChunks], n_chunks);
@@ -534,6 +538,83 @@ __global__ void __launch_bounds__(256, COUNT ? 1 : RTX_WAVES_PER_SIMD) shadow_ke
     if (COUNT && lane == 0) flush_counters<COUNT>(counters, 0ull, wc);
 }
 
+// Stream ray of a chunk for the packed kernel: (hit pixel, sample) of ray number `ray`, its origin and direction.
+struct StreamRay {
+    uint32_t hp, si;
+    bool valid;
+    float hx, hy, hz, sx, sy, sz, nx, ny, nz, dist_light;
+};
+
+__device__ __forceinline__ StreamRay stream_ray(const DeviceScene &S, const StreamWorkspace &W, const TileDesc &td,
+                                                uint32_t r, uint32_t ray)
+{
+    StreamRay s;
+    const uint32_t total = td.n_hit * S.nb_light;
+    const bool sample_major = (td.flags & 1u) != 0u;
+    const uint32_t div = sample_major ? td.n_hit : S.nb_light;
+    s.valid = ray < total;
+    const uint32_t quo = s.valid ? ray / div : 0u;
+    const uint32_t rem = s.valid ? ray - quo * div : 0u;
+    s.hp = sample_major ? rem : quo;
+    s.si = sample_major ? quo : rem;
+    const HitRec *h = W.hits + (td.first + s.hp);
+    s.hx = h->p[0]; s.hy = h->p[1]; s.hz = h->p[2];
+    s.nx = h->n[0]; s.ny = h->n[1]; s.nz = h->n[2];
+    const float *lp = S.light_points + 3u * (r * S.nb_light + s.si);                 // main.rs:194-196 (hoisted)
+    const float vx = lp[0] - s.hx, vy = lp[1] - s.hy, vz = lp[2] - s.hz;             // p - orig
+    s.dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                               // main.rs:202
+    s.sx = vx / s.dist_light; s.sy = vy / s.dist_light; s.sz = vz / s.dist_light;    // main.rs:201
+    return s;
+}
+
+__device__ __forceinline__ void stream_result(const DeviceScene &S, const StreamWorkspace &W, const TileDesc &td,
+                                              const StreamRay &s, float best_t, uint32_t best_idx)
+{
+    const float lnd = fabsf(s.nx * s.sx + s.ny * s.sy + s.nz * s.sz);                // main.rs:207
+    bool lit = true;                                                                  // main.rs:229-231
+    if (best_idx != kNone) {                                                          // main.rs:219-227
+        const float qx = s.hx - (s.hx + best_t * s.sx), qy = s.hy - (s.hy + best_t * s.sy),
+                    qz = s.hz - (s.hz + best_t * s.sz);
+        lit = sqrtf(qx * qx + qy * qy + qz * qz) > s.dist_light;
+    }
+    if (s.valid) W.results[(size_t)td.first * S.nb_light + (size_t)s.si * td.n_hit + s.hp] = lit ? lnd : kOccluded;
+}
+
+// shadow_kernel with two rays per lane: a chunk is 128 consecutive rays of a tile, lane l carries rays l and 64+l
+// as the halves of packed f32 registers (closest_hit2).
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(256, COUNT ? 1 : RTX_PACKED_WAVES_PER_SIMD)
+shadow2_kernel(DeviceScene S, uint32_t r, StreamWorkspace W, uint32_t *__restrict__ queue,
+               unsigned long long *__restrict__ counters)
+{
+    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = W.ctr[kCtrChunks];
+    WaveCounters wc;
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t c = __builtin_amdgcn_readfirstlane(wave_id); c < n_chunks; c += n_waves) {
+        const uint2 cd = W.chunks[c];
+        const TileDesc td = W.tiles[cd.x];
+        const StreamRay a = stream_ray(S, W, td, r, cd.y * 128u + lane);
+        const StreamRay b = stream_ray(S, W, td, r, cd.y * 128u + 64u + lane);
+        LaneRay2 pr = make_ray2(a.valid, b.valid, f2{a.hx, b.hx}, f2{a.hy, b.hy}, f2{a.hz, b.hz},
+                                f2{a.sx, b.sx}, f2{a.sy, b.sy}, f2{a.sz, b.sz});
+        const bool ok = closest_hit2<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:204
+        if (!ok) {   // a hard direction in this chunk: queue the tile once for the reference re-render
+            if (lane == 0 && (atomicOr(&W.tiles[cd.x].flags, 2u) & 2u) == 0u) {
+                queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = cd.x;
+                if (COUNT && counters) atomicAdd(&counters[5], 1ull);
+            }
+            continue;
+        }
+        stream_result(S, W, td, a, pr.best_t.x, pr.best_idx0);
+        stream_result(S, W, td, b, pr.best_t.y, pr.best_idx1);
+    }
+    if (COUNT && lane == 0) flush_counters<COUNT>(counters, 0ull, wc);
+}
+
 __global__ void __launch_bounds__(64) accumulate_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t r,
                                                         StreamWorkspace W, uint8_t *__restrict__ out)
 {
@@ -570,7 +651,7 @@ __global__ void __launch_bounds__(64) accumulate_kernel(DeviceScene S, TileSpec 
 
 namespace {
 
-template <bool COUNT, bool FAST>
+template <bool COUNT, bool FAST, bool PACKED>
 hipError_t launch_stream(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                          const StreamWorkspace &W, unsigned long long *d_counters, hipStream_t stream)
 {
@@ -582,7 +663,9 @@ hipError_t launch_stream(const DeviceScene &S, const TileSpec &ts, uint8_t *d_ou
     if (e != hipSuccess) return e;
     if (dev != cached_dev) {
         int per_cu = 0, cus = 0;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shadow_kernel<COUNT, FAST>, 256, 0)) != hipSuccess) return e;
+        e = PACKED ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shadow2_kernel<COUNT, FAST>, 256, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shadow_kernel<COUNT, FAST>, 256, 0);
+        if (e != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         cached_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
         cached_dev = dev;
@@ -590,11 +673,16 @@ hipError_t launch_stream(const DeviceScene &S, const TileSpec &ts, uint8_t *d_ou
     if ((e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream)) != hipSuccess) return e;
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         if ((e = hipMemsetAsync(W.ctr, 0, kStreamCtrWords * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((primary_kernel<COUNT, FAST>), dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, r, W, d_redo,
-                           d_counters);
-        if (S.nb_light)
-            hipLaunchKernelGGL((shadow_kernel<COUNT, FAST>), dim3(cached_blocks), dim3(256), 0, stream, S, r, W, d_redo,
-                               d_counters);
+        hipLaunchKernelGGL((primary_kernel<COUNT, FAST>), dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, r,
+                           PACKED ? 128u : 64u, W, d_redo, d_counters);
+        if (S.nb_light) {
+            if (PACKED)
+                hipLaunchKernelGGL((shadow2_kernel<COUNT, FAST>), dim3(cached_blocks), dim3(256), 0, stream, S, r, W,
+                                   d_redo, d_counters);
+            else
+                hipLaunchKernelGGL((shadow_kernel<COUNT, FAST>), dim3(cached_blocks), dim3(256), 0, stream, S, r, W,
+                                   d_redo, d_counters);
+        }
         hipLaunchKernelGGL(accumulate_kernel, dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, r, W, d_out);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
@@ -686,11 +774,19 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 {
     if (ts.local_rows == 0) return hipSuccess;
     if ((variant & kVariantStream) && ws && !d_wave_prof) {
-        if (d_counters)
-            return (variant & 1u) ? launch_stream<true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
-                                  : launch_stream<true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
-        return (variant & 1u) ? launch_stream<false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
-                              : launch_stream<false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+        const bool fast = (variant & 1u) != 0u, packed = (variant & kVariantPacked) != 0u;
+        if (d_counters) {
+            if (packed)
+                return fast ? launch_stream<true, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                            : launch_stream<true, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+            return fast ? launch_stream<true, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                        : launch_stream<true, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+        }
+        if (packed)
+            return fast ? launch_stream<false, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                        : launch_stream<false, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+        return fast ? launch_stream<false, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                    : launch_stream<false, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
     }
     if (d_counters || d_wave_prof)
         return launch_select<true>(variant, S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);

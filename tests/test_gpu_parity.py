@@ -281,3 +281,28 @@ def test_synthetic_soup_beyond_reference_tree(rtx, orc, samples_seeded):
         img, st = s.render_rows(stats=True)
     assert st["primary_hits"] == ost["primary_hits"] and st["redo_tiles"] == 0
     assert assert_image_close(img, ref, "synthetic 60k") == 0
+
+
+def test_every_kernel_variant_gives_the_same_bytes(samples_seeded):
+    """The kernel variants kept for ablation (exact vs multiply-based culling, 1/2/4/8 wavefronts per tile, the
+    streamed three-kernel pipeline, two rays per lane with packed f32) must all reproduce the golden image.
+    RTX_VARIANT is read once per process, so each variant renders in its own child process (one at a time)."""
+    import subprocess
+    import sys
+    ref, case = golden("c1b_bigbunny_256_seed")
+    code = (
+        "import importlib, sys, hashlib; sys.path.insert(0, %r)\n"
+        "rtx = importlib.import_module('ray-tracer-rust_amd')\n"
+        "s = rtx.default_scene([%r], 256, 256, rtx.gen_samples())\n"
+        "img, st = s.render_rows(stats=True)\n"
+        "print('RESULT', hashlib.sha1(img.tobytes()).hexdigest(), st['primary_hits'], st['rays'])\n"
+    ) % (ROOT, model("big_bunny.obj"))
+    import hashlib
+    want = hashlib.sha1(np.ascontiguousarray(ref).tobytes()).hexdigest()
+    for variant in (0, 1, 2, 3, 5, 7, 8, 9, 25):
+        env = dict(os.environ, RTX_VARIANT=str(variant))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, (variant, out.stderr[-800:])
+        _, sha, hits, rays = line[0].split()
+        assert sha == want and int(hits) == case["primary_hits"] and int(rays) == case["r_total"], (variant, line[0])
