@@ -206,6 +206,11 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch_n%d" % world)
+        pmc = None      # SQ counters of an earlier profiled run of the same workload (profiles/pmc_summary.json)
+        ppath = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(ppath) and world == 1:
+            with open(ppath) as f:
+                pmc = json.load(f).get(args.workload)
         line = {
             "metric": "Mrays/sec + frame ms, big_bunny.obj @ 1920x1080" if args.workload == "c3"
                       else "Mrays/sec + frame ms, " + wl["desc"],
@@ -232,6 +237,11 @@ def main():
                          "survey_b_alg_frac": round(b_alg_brute / world / kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline_valu": {"bound": "fp32-valu", "achieved": round(ach_tf, 3), "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
+                              # 157.3 counts packed FMAs (2 lanes-ops x 2 flop); this path may neither fuse (bit parity)
+                              # nor pack much: one f32 op per lane per 4 cycles per SIMD = 39.3 Tflop/s
+                              "peak_unfused_unpacked": VALU_PEAK_TFLOPS / 4,
+                              "frac_unfused_unpacked": round(ach_tf / (VALU_PEAK_TFLOPS / 4), 5),
+                              "pmc": pmc,
                               "box_tests": box_tests, "tri_tests": tri_tests,
                               "wave_node_visits": node_visits, "wave_tri_visits": tri_visits},
         }

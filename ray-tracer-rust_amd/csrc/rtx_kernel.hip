@@ -40,8 +40,12 @@ namespace {
 #define RTX_ONE_SURFACE_SAMPLE_MAJOR 1
 #endif
 constexpr bool kOneSurfaceSampleMajor = RTX_ONE_SURFACE_SAMPLE_MAJOR != 0;
+// LDS hit record of the fused kernel: p_hit xyz, normal xyz, colour rgb, 3 spare floats
+constexpr uint32_t kHitStride = 12u;
+// Wavefronts per SIMD the register allocation is asked to allow.  8 (64 VGPRs) is 1.6 % faster on C3 but spills
+// 68 B per lane to scratch (measured +0.3 GB of HBM traffic per frame); 6 fits in 79 VGPRs with no scratch.
 #ifndef RTX_WAVES_PER_SIMD
-#define RTX_WAVES_PER_SIMD 8
+#define RTX_WAVES_PER_SIMD 6
 #endif
 #ifndef RTX_PACKED_WAVES_PER_SIMD
 #define RTX_PACKED_WAVES_PER_SIMD 4
@@ -107,7 +111,7 @@ __device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit,
     const uint32_t rem = valid ? ray - quo * div : 0u;
     s.hp = sample_major ? rem : quo;     // compacted hit pixel
     s.si = sample_major ? quo : rem;     // light sample within the batch
-    const float *h = l_hit + 8u * s.hp;
+    const float *h = l_hit + kHitStride * s.hp;
     const float hx = h[0], hy = h[1], hz = h[2];
     const float vx = l_light[3u * s.si] - hx, vy = l_light[3u * s.si + 1u] - hy, vz = l_light[3u * s.si + 2u] - hz;   // p - orig
     s.dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                               // main.rs:202
@@ -119,7 +123,7 @@ __device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit,
 __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, float *__restrict__ l_res,
                                               uint32_t res_stride, const ShadowRay &s)
 {
-    const float *h = l_hit + 8u * s.hp;
+    const float *h = l_hit + kHitStride * s.hp;
     const LaneRay &r = s.ray;
     const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
     bool lit = true;                                                                  // main.rs:229-231
@@ -157,7 +161,10 @@ __device__ __forceinline__ void flush_counters(unsigned long long *__restrict__ 
 // LDS image of a workgroup (floats): light points of the current batch [3*batch], hit records
 // [64][8] = {p_hit.xyz, normal.xyz, -, -}, sample results [64][res_stride], {hit count, redo flag}.
 __host__ __device__ inline uint32_t lds_res_stride(uint32_t batch) { return batch | 1u; }   // odd: conflict-free column reads
-__host__ __device__ inline uint32_t lds_floats(uint32_t batch) { return 3u * batch + 64u * 8u + 64u * lds_res_stride(batch) + 4u; }
+__host__ __device__ inline uint32_t lds_floats(uint32_t batch)
+{
+    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u;
+}
 
 // Second launch bound = wavefronts per SIMD the register allocation must allow: 8 (64 VGPRs) for the
 // shipped kernel — the traversal is a chain of dependent scalar loads, resident waves are what hides it.
@@ -170,9 +177,10 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     extern __shared__ __align__(16) float lds[];
     float *const l_light = lds;
     float *const l_hit = l_light + 3u * batch;
-    float *const l_res = l_hit + 64u * 8u;
+    float *const l_res = l_hit + 64u * kHitStride;
     const uint32_t res_stride = lds_res_stride(batch);
-    uint32_t *const l_ctl = reinterpret_cast<uint32_t *>(l_res + 64u * res_stride);   // [0] hit count, [1] redo flag
+    float *const l_pix = l_res + 64u * res_stride;                                    // per pixel: running sums r,g,b + hit slot
+    uint32_t *const l_ctl = reinterpret_cast<uint32_t *>(l_pix + 64u * 4u);           // [0] hit count, [1] redo flag, [2] numbering, [3] tile
 
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
@@ -197,42 +205,42 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     if (q >= n_tiles) break;
     const uint32_t tile_x = q % tiles_x;
     const uint32_t tile_y = tiles_y - 1u - q / tiles_x;
-    uint32_t px, py, ly;
-    const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
 
     unsigned long long t_start = 0, t_mark = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0;   // diagnostics (COUNT builds)
     if (COUNT) t_start = wall_clock64();
     unsigned long long primary_hits = 0;
     const unsigned long long nv0 = wc.node_visits, tv0 = wc.tri_visits;
 
-    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;                                  // main.rs:182 (wave 0 only)
+    // Per-pixel state (running sums, hit slot, colour) is parked in LDS between the phases: every wavefront
+    // of the workgroup runs phase 2, and registers that only wave 0 needs afterwards would be live in all of
+    // them (the kernel is built for 8 wavefronts per SIMD = 64 VGPRs).
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         // ---------------- phase 1: primary rays, one work-item per pixel (wave 0) ----------------
-        bool hit = false;
-        uint32_t slot = 0;
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
         if (wave == 0) {
-            float dx, dy, dz, t;
-            uint32_t idx;
+            uint32_t px, py, ly;
+            const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
+            float dx, dy, dz;
             if (COUNT) t_mark = wall_clock64();
             primary_ray(S, in_frame, px, py, r, dx, dy, dz);
             LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
             const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
-            t = pr.best_t;
-            idx = pr.best_idx;
-            hit = in_frame && idx != kNone;
+            const float t = pr.best_t;
+            const uint32_t idx = pr.best_idx;
+            const bool hit = in_frame && idx != kNone;
             const unsigned long long hit_mask = __ballot(hit);
-            slot = __popcll(hit_mask & ((1ull << lane) - 1ull));                      // compacted index of this pixel
+            const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));       // compacted index of this pixel
             if (COUNT) primary_hits += __popcll(hit_mask);
             if (hit) {
                 const ShadeRec sh = S.shade[idx];
-                float *h = l_hit + 8u * slot;
+                float *h = l_hit + kHitStride * slot;
                 h[0] = S.eye[0] + t * dx;                                             // p_hit, bvh.rs:69
                 h[1] = S.eye[1] + t * dy;
                 h[2] = S.eye[2] + t * dz;
                 h[3] = sh.normal[0]; h[4] = sh.normal[1]; h[5] = sh.normal[2];        // main.rs:206
-                cr = sh.rgb[0]; cg = sh.rgb[1]; cb = sh.rgb[2];                       // main.rs:191
+                h[6] = sh.rgb[0]; h[7] = sh.rgb[1]; h[8] = sh.rgb[2];                 // main.rs:191
             }
+            if (r == 0u) { l_pix[4u * lane] = 0.0f; l_pix[4u * lane + 1u] = 0.0f; l_pix[4u * lane + 2u] = 0.0f; }   // main.rs:182
+            reinterpret_cast<uint32_t *>(l_pix)[4u * lane + 3u] = hit ? slot : kNone;
             // Ray numbering of phase 2.  All hit pixels on ONE triangle (the ground, a wall): the 64 pixels of a
             // sample make the tighter shaft (neighbouring surface points -> one light point), number sample-major.
             // Several triangles (mesh surface, silhouettes): origins sit in different BVH leaves, a pixel's own
@@ -275,6 +283,11 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 // ------------- phase 3: ordered accumulation, one work-item per pixel (wave 0) -------------
                 if (COUNT) t_mark = wall_clock64();
                 if (wave == 0) {
+                    const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
+                    const bool hit = slot != kNone;
+                    float acc_r = l_pix[4u * lane], acc_g = l_pix[4u * lane + 1u], acc_b = l_pix[4u * lane + 2u];
+                    const float *h = l_hit + kHitStride * (hit ? slot : 0u);
+                    const float cr = h[6], cg = h[7], cb = h[8];
                     // grey surfaces (every BASELINE scene): the three channel sums are the same f32 sequence
                     const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && acc_r == acc_g && acc_g == acc_b)) == 0ull;
                     if (hit) {
@@ -307,6 +320,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                                 }
                             }
                         }
+                        l_pix[4u * lane] = acc_r; l_pix[4u * lane + 1u] = acc_g; l_pix[4u * lane + 2u] = acc_b;
                     }
                 }
                 if (COUNT && wave == 0) t_ph3 += wall_clock64() - t_mark;
@@ -323,8 +337,10 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_y * tiles_x + tile_x;
                 if (COUNT && counters) atomicAdd(&counters[5], 1ull);
             }
-        } else if (in_frame) {
-            store_pixel(S, out, px, ly, acc_r, acc_g, acc_b);
+        } else {
+            uint32_t px, py, ly;
+            if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly))
+                store_pixel(S, out, px, ly, l_pix[4u * lane], l_pix[4u * lane + 1u], l_pix[4u * lane + 2u]);
         }
     }
     primary_hits_total += primary_hits;

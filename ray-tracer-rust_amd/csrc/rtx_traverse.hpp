@@ -90,6 +90,26 @@ __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float
     return !(t_in - t_out > slack) && !(t_out < -0x1p-100f);   // written so that a NaN can only accept
 }
 
+// slab_fast with one fused multiply-add per plane: t = fma(plane, 1/d, -(o*(1/d))).  Culling only — no pixel
+// value depends on these numbers — so a fused operation is allowed here.  Against the exact quotient q:
+//   t = T(1+e_r)(1+e_f) - (o/d)(1+e_r) e_m,  T = (plane-o)/d,   |t - q| <= 4*2^-24 |t| + 1.01*2^-24 |o/d|
+// (e_r: rounding of 1/d, e_m: of o*(1/d), e_f: of the fma).  The second term does not shrink with t, so the
+// ray carries E = 2^-21 (|ox/dx| + |oy/dy| + |oz/dz|) + 2^-100 and the box is rejected only if
+//   t_in - t_out > 2^-20 (|t_in| + |t_out|) + E      or      t_out < -1.00001 E ,
+// four times the bound.  Origin inside the box: every near <= E-ish <= every far, never rejected.
+__device__ __forceinline__ bool slab_fast_fma(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                              float ix, float iy, float iz, float nx, float ny, float nz,
+                                              float slack0, float behind)
+{
+    const float ax = __builtin_fmaf(lox, ix, nx), bx = __builtin_fmaf(hix, ix, nx);
+    const float ay = __builtin_fmaf(loy, iy, ny), by = __builtin_fmaf(hiy, iy, ny);
+    const float az = __builtin_fmaf(loz, iz, nz), bz = __builtin_fmaf(hiz, iz, nz);
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, slack0);
+    return !(t_in - t_out > slack) && !(t_out < behind);   // written so that a NaN can only accept
+}
+
 // a node record through the constant address space (scalar loads); field-wise because a struct copy
 // across address spaces has no implicit constructor
 __device__ __forceinline__ NodeRec load_node(const NodeRec RTX_CONSTANT *p)
@@ -207,6 +227,8 @@ struct LaneRay {
     float ox, oy, oz;     // origin
     float dx, dy, dz;     // unit direction (Ray::new)
     float ix, iy, iz;     // 1/d, used by the multiply-based culling only
+    float nx, ny, nz;     // -(o * 1/d)                       "
+    float slack0, behind; // E and -1.00001 E of slab_fast_fma "
     float best_t;         // minimum accepted distance so far
     uint32_t best_idx;    // caller-order index of its triangle, kNone = no hit
     bool active;          // lanes without a ray never vote
@@ -218,16 +240,30 @@ __device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, flo
     r.ox = ox; r.oy = oy; r.oz = oz;
     r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
+    r.nx = -px; r.ny = -py; r.nz = -pz;
+    r.slack0 = __builtin_fmaf(fabsf(px) + fabsf(py) + fabsf(pz), 0x1p-21f, 0x1p-100f);
+    r.behind = -1.00001f * r.slack0;
     r.best_t = __builtin_inff();
     r.best_idx = kNone;
     r.active = active;
     return r;
 }
 
+#ifndef RTX_CULL_FMA
+#define RTX_CULL_FMA 1
+#endif
+
 __device__ __forceinline__ bool box_pass(bool use_fast, const NodeRec &n, const LaneRay &r)
 {
-    if (use_fast)
+    if (use_fast) {
+#if RTX_CULL_FMA
+        return slab_fast_fma(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ix, r.iy, r.iz,
+                             r.nx, r.ny, r.nz, r.slack0, r.behind);
+#else
         return slab_fast(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
+#endif
+    }
     return slab_exact(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
 }
 
