@@ -69,11 +69,16 @@ static inline float distance(v3 a, v3 b) { return norm(sub(a, b)); }
 /* ------------------------------------------------------------------ */
 /* scene types                                                          */
 
+/* enum Primitive { Sphere, Triangle } — src/tracer/primitives/mod.rs:40-43.  One record type for both
+ * arms: the triangle fields (triangle.rs:11-19) or the sphere fields (sphere.rs:12-18) are used. */
 typedef struct {
     v3 v0, v1, v2;
     v3 color;
     v3 normal;
     v3 e1, e2;
+    int is_sphere;
+    v3 center;              /* Sphere.origin */
+    float radius, radius2;
 } tri_t;
 
 typedef struct { v3 min, max; } bbox_t;
@@ -138,12 +143,53 @@ void orc_camera_new(const float eye[3], const float look_at[3], const float up[3
 static tri_t triangle_new(v3 v0, v3 v1, v3 v2, v3 color)
 {
     tri_t t;
+    memset(&t, 0, sizeof t);
     t.e1 = sub(v1, v0);                         /* triangle.rs:23 */
     t.e2 = sub(v2, v0);                         /* triangle.rs:24 */
     t.v0 = v0; t.v1 = v1; t.v2 = v2;
     t.normal = normalize(cross(t.e1, t.e2));    /* triangle.rs:29 */
     t.color = color;
     return t;
+}
+
+/* Sphere::new — src/tracer/primitives/sphere.rs:21-28 */
+static tri_t sphere_new(float radius, v3 origin, v3 color)
+{
+    tri_t t;
+    memset(&t, 0, sizeof t);
+    t.is_sphere = 1;
+    t.center = origin;
+    t.radius = radius;
+    t.radius2 = radius * radius;                /* sphere.rs:26 */
+    t.color = color;
+    return t;
+}
+
+/* Sphere::intersect — sphere.rs:50-83.  Returns distance(p_hit, ray.origin), not t0 (sphere.rs:81-82). */
+static int sphere_intersect(const tri_t *sp, v3 o, v3 d, float *t_out)
+{
+    v3 l = sub(sp->center, o);                  /* :54 */
+    float tca = dot(l, d);                      /* :55 */
+    if (tca < 0.0f) return 0;                   /* :56-58 */
+    float d2 = dot(l, l) - tca * tca;           /* :59 */
+    if (d2 > sp->radius2) return 0;             /* :60-62 */
+    float thc = sqrtf(sp->radius2 - d2);        /* :64 */
+    float t0 = tca - thc;                       /* :66 */
+    float t1 = tca + thc;                       /* :67 */
+    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }   /* :69-71 */
+    if (t0 < 0.0f) {                            /* :74-79 */
+        t0 = t1;
+        if (t0 < 0.0f) return 0;
+    }
+    v3 p_hit = add(o, scale(t0, d));            /* :81 */
+    *t_out = distance(p_hit, o);                /* :82 */
+    return 1;
+}
+
+int orc_sphere_intersect(const float center[3], float radius, const float o[3], const float d[3], float *t)
+{
+    tri_t sp = sphere_new(radius, ld(center), mk(1, 1, 1));
+    return sphere_intersect(&sp, ld(o), ld(d), t);
 }
 
 void orc_triangle_new(const float v0[3], const float v1[3], const float v2[3],
@@ -205,6 +251,27 @@ int orc_triangle_intersect(const float v0[3], const float e1[3], const float e2[
     memset(&tr, 0, sizeof tr);
     tr.v0 = ld(v0); tr.e1 = ld(e1); tr.e2 = ld(e2);
     return triangle_intersect(&tr, ld(o), ld(d), t);
+}
+
+/* impl Intersectable / HasBoundingBox / HasNormal for Primitive — mod.rs:45-88 (static dispatch on the arm) */
+static int prim_intersect(const tri_t *p, v3 o, v3 d, float *t_out)
+{
+    return p->is_sphere ? sphere_intersect(p, o, d, t_out) : triangle_intersect(p, o, d, t_out);
+}
+
+static bbox_t prim_bbox(const tri_t *p)
+{
+    if (!p->is_sphere) return triangle_bbox(p);
+    bbox_t b;                                   /* Sphere::get_bounding_box — sphere.rs:32-41 */
+    b.min = mk(p->center.x - p->radius, p->center.y - p->radius, p->center.z - p->radius);
+    b.max = mk(p->center.x + p->radius, p->center.y + p->radius, p->center.z + p->radius);
+    return b;
+}
+
+static v3 prim_normal(const tri_t *p, v3 at)
+{
+    if (!p->is_sphere) return p->normal;        /* mod.rs:84: t.normal */
+    return normalize(sub(at, p->center));       /* Sphere::get_normal — sphere.rs:93-95 */
 }
 
 /* Triangle::get_sample — triangle.rs:113-127 (c3 = v * u_sqrt is the reference's formula) */
@@ -337,7 +404,7 @@ static hit_t node_intersect(const orc_scene *s, int32_t ni, v3 o, v3 d, counters
     if (n->prim >= 0) {                                          /* :58 */
         float x;
         c->tri_tests++;
-        if (!triangle_intersect(&s->tris[n->prim], o, d, &x))    /* :60, :79-81 */
+        if (!prim_intersect(&s->tris[n->prim], o, d, &x))        /* :60, :79-81 -> mod.rs:64-69 */
             return none;
         if (x < 1.0f)                                            /* :64-67 */
             return none;
@@ -373,7 +440,7 @@ static int bvh_build(orc_scene *s)
     uint32_t nn = 0;
     for (uint32_t i = 0; i < n; i++) {                           /* :178-183, BVHNode::new_leaf :25-35 */
         node_t *nd = &s->nodes[nn];
-        nd->bbox = triangle_bbox(&s->tris[i]);
+        nd->bbox = prim_bbox(&s->tris[i]);
         nd->prim = (int32_t)i; nd->left = nd->right = -1;
         ext[nn] = bbox_center(&nd->bbox);
         cur[i] = (int32_t)nn++;
@@ -442,13 +509,13 @@ static hit_t closest_hit(const orc_scene *s, int mode, v3 o, v3 d, counters_t *c
     for (uint32_t i = 0; i < s->n_tris; i++) {
         float x;
         if (mode == ORC_MODE_LEAFBOX) {
-            bbox_t b = triangle_bbox(&s->tris[i]);
+            bbox_t b = prim_bbox(&s->tris[i]);
             float tb; int af = 0;
             c->slab_tests++;
             if (!bbox_intersect(&b, o, d, &tb, &af)) continue;
         }
         c->tri_tests++;
-        if (!triangle_intersect(&s->tris[i], o, d, &x)) continue;
+        if (!prim_intersect(&s->tris[i], o, d, &x)) continue;
         if (x < 1.0f) continue;
         if (!best.has || !(best.distance < x)) {
             best.has = 1; best.distance = x; best.tri = (int32_t)i;
@@ -547,7 +614,7 @@ static v3 render_pixel(const orc_scene *s, int mode, uint32_t px, uint32_t py,
         if ((uint32_t)h.tri + 1 != s->n_tris) pc->mesh_hits++;
         if (first_tri && r == 0) *first_tri = h.tri;
         v3 color = s->tris[h.tri].color;                         /* :191 */
-        v3 normal = s->tris[h.tri].normal;                       /* :206 */
+        v3 normal = prim_normal(&s->tris[h.tri], h.p_hit);       /* :206, HitInfo.normal = p.get_normal(p_hit), bvh.rs:72 */
         v3 orig = h.p_hit;                                       /* :192 */
         float denom = (float)(s->nb_ray * s->nb_light_sample);   /* :211 */
         for (uint32_t i = 0; i < s->nb_light_sample; i++) {      /* :193 */
@@ -686,19 +753,48 @@ orc_scene *orc_scene_create(uint32_t width, uint32_t height,
                             const float *samples, uint32_t n_samples,
                             int build_bvh)
 {
-    if (!n_tris || !n_samples || !v0v1v2 || !samples) return NULL;
+    return orc_scene_create_ex(width, height, eye, look_at, up, dist, light_tri, n_tris, v0v1v2, rgb, 0, NULL, NULL,
+                               NULL, nb_ray, nb_light_sample, samples, n_samples, build_bvh);
+}
+
+/* The Vec<Primitive> may mix both arms.  kinds: one byte per primitive in Vec order, 0 = the next triangle
+ * of v0v1v2/rgb, 1 = the next sphere of spheres (cx,cy,cz,radius) / sphere_rgb; NULL = triangles, then spheres. */
+orc_scene *orc_scene_create_ex(uint32_t width, uint32_t height,
+                               const float eye[3], const float look_at[3], const float up[3], float dist,
+                               const float light_tri[9],
+                               uint32_t n_tris, const float *v0v1v2, const float *rgb,
+                               uint32_t n_spheres, const float *spheres, const float *sphere_rgb,
+                               const uint8_t *kinds,
+                               uint32_t nb_ray, uint32_t nb_light_sample,
+                               const float *samples, uint32_t n_samples,
+                               int build_bvh)
+{
+    const uint32_t n_prims = n_tris + n_spheres;
+    if (!n_prims || !n_samples || !samples || (n_tris && !v0v1v2) || (n_spheres && !spheres)) return NULL;
     orc_scene *s = (orc_scene *)calloc(1, sizeof *s);
     if (!s) return NULL;
     s->width = width; s->height = height;
     s->eye = ld(eye); s->distance = dist;
     camera_new(ld(eye), ld(look_at), ld(up), &s->cam_u, &s->cam_v, &s->cam_w);
     s->light = triangle_new(ld(light_tri), ld(light_tri + 3), ld(light_tri + 6), mk(1, 1, 1));
-    s->n_tris = n_tris;
-    s->tris = (tri_t *)malloc(sizeof(tri_t) * n_tris);
-    for (uint32_t i = 0; i < n_tris; i++) {
-        const float *p = v0v1v2 + 9 * (size_t)i;
-        v3 col = rgb ? ld(rgb + 3 * (size_t)i) : mk(1, 1, 1);
-        s->tris[i] = triangle_new(ld(p), ld(p + 3), ld(p + 6), col);
+    s->n_tris = n_prims;
+    s->tris = (tri_t *)malloc(sizeof(tri_t) * n_prims);
+    uint32_t it = 0, is = 0;
+    for (uint32_t i = 0; i < n_prims; i++) {
+        const int sphere = kinds ? kinds[i] != 0 : i >= n_tris;
+        if (sphere) {
+            if (is >= n_spheres) { orc_scene_destroy(s); return NULL; }
+            const float *p = spheres + 4 * (size_t)is;
+            v3 col = sphere_rgb ? ld(sphere_rgb + 3 * (size_t)is) : mk(1, 1, 1);
+            s->tris[i] = sphere_new(p[3], ld(p), col);
+            is++;
+        } else {
+            if (it >= n_tris) { orc_scene_destroy(s); return NULL; }
+            const float *p = v0v1v2 + 9 * (size_t)it;
+            v3 col = rgb ? ld(rgb + 3 * (size_t)it) : mk(1, 1, 1);
+            s->tris[i] = triangle_new(ld(p), ld(p + 3), ld(p + 6), col);
+            it++;
+        }
     }
     s->nb_ray = nb_ray; s->nb_light_sample = nb_light_sample;
     s->n_samples = n_samples;

@@ -91,6 +91,20 @@ orc_scene *orc_scene_create(uint32_t width, uint32_t height,
                             uint32_t nb_ray, uint32_t nb_light_sample,
                             const float *samples, uint32_t n_samples,
                             int build_bvh);
+/* Vec<Primitive> with both arms (src/tracer/primitives/mod.rs:40-43).  kinds: one byte per primitive in Vec
+ * order, 0 = next triangle, 1 = next sphere (cx,cy,cz,radius); NULL = all triangles, then all spheres.
+ * Primitive indices reported by the oracle (orc_hit.tri, leaf order) are positions in that Vec. */
+orc_scene *orc_scene_create_ex(uint32_t width, uint32_t height,
+                               const float eye[3], const float look_at[3], const float up[3], float distance,
+                               const float light_tri[9],
+                               uint32_t n_tris, const float *v0v1v2, const float *rgb,
+                               uint32_t n_spheres, const float *spheres, const float *sphere_rgb,
+                               const uint8_t *kinds,
+                               uint32_t nb_ray, uint32_t nb_light_sample,
+                               const float *samples, uint32_t n_samples,
+                               int build_bvh);
+/* Sphere::intersect (sphere.rs:50-83): 1 = Some(*t) where t = distance(p_hit, origin) */
+int  orc_sphere_intersect(const float center[3], float radius, const float o[3], const float d[3], float *t);
 void orc_scene_destroy(orc_scene *s);
 uint32_t orc_bvh_node_count(const orc_scene *s);
 uint32_t orc_bvh_depth(const orc_scene *s);

@@ -68,6 +68,12 @@ def lib():
     L.orc_scene_create.restype = C.c_void_p
     L.orc_scene_create.argtypes = [C.c_uint32, C.c_uint32, f32p, f32p, f32p, C.c_float, f32p,
                                    C.c_uint32, f32p, f32p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_int]
+    L.orc_scene_create_ex.restype = C.c_void_p
+    L.orc_scene_create_ex.argtypes = [C.c_uint32, C.c_uint32, f32p, f32p, f32p, C.c_float, f32p,
+                                      C.c_uint32, f32p, f32p, C.c_uint32, f32p, f32p, C.c_void_p,
+                                      C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_int]
+    L.orc_sphere_intersect.argtypes = [f32p, C.c_float, f32p, f32p, f32p]
+    L.orc_sphere_intersect.restype = C.c_int
     L.orc_scene_destroy.argtypes = [C.c_void_p]
     L.orc_bvh_node_count.argtypes = [C.c_void_p]
     L.orc_bvh_node_count.restype = C.c_uint32
@@ -140,17 +146,25 @@ def default_primitives(obj_names):
 class Scene:
     def __init__(self, width, height, tris, rgb, samples, *, eye=EYE, look_at=LOOK_AT, up=UP,
                  distance=DISTANCE, light_tri=LIGHT_TRI, nb_ray=NB_RAY,
-                 nb_light_sample=NB_LIGHT_SAMPLE, build_bvh=True):
+                 nb_light_sample=NB_LIGHT_SAMPLE, build_bvh=True, spheres=None, sphere_rgb=None, kinds=None):
         self.width, self.height = int(width), int(height)
         self.tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
         self.rgb = np.ascontiguousarray(rgb, dtype=np.float32).reshape(-1, 3)
         self.samples = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, 2)
-        self.n_tris = len(self.tris)
+        self.spheres = np.zeros((0, 4), np.float32) if spheres is None else \
+            np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+        self.sphere_rgb = np.ones((len(self.spheres), 3), np.float32) if sphere_rgb is None else \
+            np.ascontiguousarray(sphere_rgb, dtype=np.float32).reshape(-1, 3)
+        self.kinds = None if kinds is None else np.ascontiguousarray(kinds, dtype=np.uint8)
+        self.n_tris = len(self.tris) + len(self.spheres)       # primitives in the Vec (both arms)
         lt = np.ascontiguousarray(np.asarray(light_tri, dtype=np.float32).reshape(9))
-        self.h = lib().orc_scene_create(self.width, self.height, _fp(f3(eye)), _fp(f3(look_at)),
-                                        _fp(f3(up)), float(distance), _fp(lt), self.n_tris,
-                                        _fp(self.tris), _fp(self.rgb), nb_ray, nb_light_sample,
-                                        _fp(self.samples), len(self.samples), int(build_bvh))
+        self.h = lib().orc_scene_create_ex(self.width, self.height, _fp(f3(eye)), _fp(f3(look_at)),
+                                           _fp(f3(up)), float(distance), _fp(lt), len(self.tris),
+                                           _fp(self.tris), _fp(self.rgb), len(self.spheres), _fp(self.spheres),
+                                           _fp(self.sphere_rgb),
+                                           self.kinds.ctypes.data if self.kinds is not None else None,
+                                           nb_ray, nb_light_sample,
+                                           _fp(self.samples), len(self.samples), int(build_bvh))
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
 
