@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 2
+#define RTX_ABI_VERSION 3
 
 typedef enum RtxError {
     RTX_OK              =  0,
@@ -102,6 +102,13 @@ typedef struct RtxSceneDesc {
     uint32_t accel;             /* RTX_ACCEL_* */
     uint32_t leaf_max;          /* max triangles per BVH leaf; 0 = library default */
     uint32_t reference_tree;    /* RTX_REFTREE_* */
+    /* Sphere arm of Primitive (src/tracer/primitives/sphere.rs:12-29); n_spheres = 0 for the reference's main() */
+    uint32_t n_spheres;
+    const float *spheres;       /* n_spheres x 4: origin x,y,z, radius */
+    const float *sphere_rgb;    /* n_spheres x 3 */
+    const uint8_t *kinds;       /* order of the Vec<Primitive>: n_tris + n_spheres bytes, 0 = next triangle,
+                                   1 = next sphere; NULL = all triangles, then all spheres.  Primitive indices
+                                   (tie_rank entries, statistics) are positions in that Vec. */
 } RtxSceneDesc;
 
 typedef struct RtxStats {
@@ -184,7 +191,8 @@ int rtx_last_hip_error(void);
 int rtx_scene_light_points(const RtxScene *scene, float *out);
 /* out: 256 floats; byte value of a linear channel x = number of thresholds b>=1 with thr[b] <= x */
 int rtx_scene_gamma_thresholds(const RtxScene *scene, float *out256);
-/* out: n_tris x 3 unit normals in input order (Triangle::new, triangle.rs:29) */
+/* out: (n_tris + n_spheres) x 3 in Vec order: unit normal of a triangle (Triangle::new, triangle.rs:29),
+   origin of a sphere (its normal is normalize(p_hit - origin), sphere.rs:93-95) */
 int rtx_scene_normals(const RtxScene *scene, float *out);
 /* the traversal stream: node records (8 dwords each) and the triangle order of the leaves */
 int rtx_scene_nodes(const RtxScene *scene, uint32_t *out_dwords /* n_nodes*8 */, uint32_t *out_tri_order /* n_tris */);

@@ -155,6 +155,7 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     S.height = p.height;
     S.nb_ray = p.nb_ray;
     S.nb_light = p.nb_light_sample;
+    S.n_spheres = p.n_spheres;
     std::memcpy(S.eye, p.eye, 12);
     std::memcpy(S.cu, p.cam_u, 12);
     std::memcpy(S.cv, p.cam_v, 12);

@@ -94,6 +94,23 @@ __device__ __forceinline__ void primary_ray(const DeviceScene &S, bool in_frame,
     dz = rz / rn;
 }
 
+// HitInfo.normal = p.get_normal(p_hit) (bvh.rs:72, mod.rs:80-87): the stored normal of a triangle (triangle.rs:29),
+// normalize(p_hit - origin) for a sphere (sphere.rs:93-95; the record holds the origin in its normal field)
+template <bool SPHERES>
+__device__ __forceinline__ void hit_normal(const ShadeRec &sh, float hx, float hy, float hz, float &nx, float &ny, float &nz)
+{
+    nx = sh.normal[0];
+    ny = sh.normal[1];
+    nz = sh.normal[2];
+    if (SPHERES && sh.kind != 0u) {
+        const float vx = hx - nx, vy = hy - ny, vz = hz - nz;
+        const float n = sqrtf(dot_zero_first(vx, vy, vz, vx, vy, vz));
+        nx = vx / n;
+        ny = vy / n;
+        nz = vz / n;
+    }
+}
+
 // One shadow ray of phase 2: ray number -> (compacted hit pixel, light sample), origin = the pixel's hit
 // point, direction = towards the light point (main.rs:194-202).
 struct ShadowRay {
@@ -168,7 +185,7 @@ __host__ __device__ inline uint32_t lds_floats(uint32_t batch)
 
 // Second launch bound = wavefronts per SIMD the register allocation must allow: 8 (64 VGPRs) for the
 // shipped kernel — the traversal is a chain of dependent scalar loads, resident waves are what hides it.
-template <bool COUNT, bool FAST, int NW>
+template <bool COUNT, bool FAST, int NW, bool SPHERES = false>
 __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_WAVES_PER_SIMD)
 trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x, uint32_t tiles_y,
                    uint8_t *__restrict__ out, uint32_t *__restrict__ queue,
@@ -223,7 +240,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             if (COUNT) t_mark = wall_clock64();
             primary_ray(S, in_frame, px, py, r, dx, dy, dz);
             LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
-            const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
+            const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
             const float t = pr.best_t;
             const uint32_t idx = pr.best_idx;
             const bool hit = in_frame && idx != kNone;
@@ -236,7 +253,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 h[0] = S.eye[0] + t * dx;                                             // p_hit, bvh.rs:69
                 h[1] = S.eye[1] + t * dy;
                 h[2] = S.eye[2] + t * dz;
-                h[3] = sh.normal[0]; h[4] = sh.normal[1]; h[5] = sh.normal[2];        // main.rs:206
+                hit_normal<SPHERES>(sh, h[0], h[1], h[2], h[3], h[4], h[5]);                   // main.rs:206
                 h[6] = sh.rgb[0]; h[7] = sh.rgb[1]; h[8] = sh.rgb[2];                 // main.rs:191
             }
             if (r == 0u) { l_pix[4u * lane] = 0.0f; l_pix[4u * lane + 1u] = 0.0f; l_pix[4u * lane + 2u] = 0.0f; }   // main.rs:182
@@ -273,7 +290,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 //  slower, 4.3 vs 3.7 ms on C3: it needs ~105 VGPRs, and resident wavefronts hide more latency)
                 for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                     ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
-                    const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
+                    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
                     if (!ok && lane == 0) l_ctl[1] = 1u;
                     shadow_result(l_hit, l_res, res_stride, sr);
                 }
@@ -364,7 +381,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 // One wavefront per queued tile, one work-item per pixel, the reference's loop order (main.rs:180-240)
 // with the literal reference traversal.  Slow by construction (the reference's tree visits thousands of
 // boxes per ray); only tiles holding a zero-component ray come here.
-template <bool COUNT>
+template <bool COUNT, bool SPHERES = false>
 __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x,
                                                               uint8_t *__restrict__ out,
                                                               const uint32_t *__restrict__ redo,
@@ -388,7 +405,7 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
             float dx, dy, dz, t;
             uint32_t idx;
             primary_ray(S, in_frame, px, py, r, dx, dy, dz);
-            closest_hit_reference<COUNT>(stream, tris, S.shade, n_stream, have_ref, in_frame, S.eye[0], S.eye[1], S.eye[2],
+            closest_hit_reference<COUNT, SPHERES>(stream, tris, S.shade, n_stream, have_ref, in_frame, S.eye[0], S.eye[1], S.eye[2],
                                          dx, dy, dz, t, idx, wc);
             const bool hit = in_frame && idx != kNone;
             const unsigned long long hit_mask = __ballot(hit);
@@ -400,7 +417,7 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
                 hy = S.eye[1] + t * dy;
                 hz = S.eye[2] + t * dz;
                 const ShadeRec sh = S.shade[idx];
-                nx = sh.normal[0]; ny = sh.normal[1]; nz = sh.normal[2];
+                hit_normal<SPHERES>(sh, hx, hy, hz, nx, ny, nz);
                 cr = sh.rgb[0]; cg = sh.rgb[1]; cb = sh.rgb[2];
             }
             for (uint32_t i = 0; i < S.nb_light; ++i) {
@@ -410,7 +427,7 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
                 const float sx = vx / dist_light, sy = vy / dist_light, sz = vz / dist_light;
                 float st;
                 uint32_t sidx;
-                closest_hit_reference<COUNT>(stream, tris, S.shade, n_stream, have_ref, hit, hx, hy, hz, sx, sy, sz,
+                closest_hit_reference<COUNT, SPHERES>(stream, tris, S.shade, n_stream, have_ref, hit, hx, hy, hz, sx, sy, sz,
                                              st, sidx, wc);
                 const float lnd = fabsf(nx * sx + ny * sy + nz * sz);
                 bool lit = true;
@@ -489,7 +506,7 @@ __global__ void __launch_bounds__(64) primary_kernel(DeviceScene S, TileSpec ts,
         h.p[0] = S.eye[0] + pr.best_t * dx;                                          // p_hit, bvh.rs:69
         h.p[1] = S.eye[1] + pr.best_t * dy;
         h.p[2] = S.eye[2] + pr.best_t * dz;
-        h.n[0] = sh.normal[0]; h.n[1] = sh.normal[1]; h.n[2] = sh.normal[2];         // main.rs:206
+        hit_normal<false>(sh, h.p[0], h.p[1], h.p[2], h.n[0], h.n[1], h.n[2]);              // main.rs:206
         h.rgb[0] = sh.rgb[0]; h.rgb[1] = sh.rgb[1]; h.rgb[2] = sh.rgb[2];            // main.rs:191
         h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
         W.hits[first + slot] = h;
@@ -707,7 +724,7 @@ hipError_t launch_stream(const DeviceScene &S, const TileSpec &ts, uint8_t *d_ou
     return hipGetLastError();
 }
 
-template <bool COUNT, bool FAST, int NW>
+template <bool COUNT, bool FAST, int NW, bool SPHERES = false>
 hipError_t launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                           unsigned long long *d_counters, unsigned long long *d_wave_prof, hipStream_t stream)
 {
@@ -725,7 +742,7 @@ hipError_t launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_o
     if (e != hipSuccess) return e;
     if (dev != cached_dev || lds_bytes != cached_lds) {
         int per_cu = 0, cus = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_shade_kernel<COUNT, FAST, NW>, 64 * NW, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_shade_kernel<COUNT, FAST, NW, SPHERES>, 64 * NW, lds_bytes);
         if (e != hipSuccess) return e;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
@@ -736,10 +753,10 @@ hipError_t launch_variant(const DeviceScene &S, const TileSpec &ts, uint8_t *d_o
     const uint32_t grid = n_tiles < static_cast<uint32_t>(cached_blocks) ? n_tiles : static_cast<uint32_t>(cached_blocks);
     e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream);   // redo count, next tile
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, NW>), dim3(grid), block, lds_bytes, stream, S, ts, batch, tiles_x,
+    hipLaunchKernelGGL((trace_shade_kernel<COUNT, FAST, NW, SPHERES>), dim3(grid), block, lds_bytes, stream, S, ts, batch, tiles_x,
                        tiles_y, d_out, d_redo, d_counters, d_wave_prof);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL((reference_tiles_kernel<COUNT>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream, S,
+    hipLaunchKernelGGL((reference_tiles_kernel<COUNT, SPHERES>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream, S,
                        ts, tiles_x, d_out, d_redo, d_counters);
     return hipGetLastError();
 }
@@ -748,6 +765,10 @@ template <bool COUNT>
 hipError_t launch_select(uint32_t variant, const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                          unsigned long long *d_counters, unsigned long long *d_wave_prof, hipStream_t stream)
 {
+    // scenes holding spheres: the kernels with the Sphere arm compiled in, at the default workgroup shape only
+    if (S.n_spheres)
+        return (variant & 1u) ? launch_variant<COUNT, true, 8, true>(S, ts, d_out, d_redo, d_counters, d_wave_prof, stream)
+                              : launch_variant<COUNT, false, 8, true>(S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
     switch (variant & 7u) {
     case 0: return launch_variant<COUNT, false, 4>(S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
     case 1: return launch_variant<COUNT, true, 4>(S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
@@ -789,7 +810,7 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
                               unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream)
 {
     if (ts.local_rows == 0) return hipSuccess;
-    if ((variant & kVariantStream) && ws && !d_wave_prof) {
+    if ((variant & kVariantStream) && ws && !d_wave_prof && S.n_spheres == 0u) {   // the streamed kernels are triangle-only
         const bool fast = (variant & 1u) != 0u, packed = (variant & kVariantPacked) != 0u;
         if (d_counters) {
             if (packed)

@@ -147,6 +147,42 @@ __device__ __forceinline__ bool direction_is_hard(float dx, float dy, float dz)
     return !(component_is_soft_or_regular(dx) && component_is_soft_or_regular(dy) && component_is_soft_or_regular(dz));
 }
 
+// nalgebra 0.11 dot: the accumulator starts at zero, terms are added in x, y, z order
+__device__ __forceinline__ float dot_zero_first(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float acc = 0.0f;
+    acc = acc + ax * bx;
+    acc = acc + ay * by;
+    acc = acc + az * bz;
+    return acc;
+}
+
+// Sphere::intersect — sphere.rs:50-83, branch-free: the early `return None`s become the returned mask.
+// sp is a TriRec slot holding a sphere (v0 = origin, e1[0] = radius2).  *t = distance(p_hit, ray.origin),
+// recomputed from p_hit = origin + t0 * direction as the reference does (:81-82), not t0 itself.
+__device__ __forceinline__ bool sphere_distance(const TriRec RTX_CONSTANT *sp, float ox, float oy, float oz,
+                                                float dx, float dy, float dz, float &t)
+{
+    const float radius2 = sp->e1[0];
+    const float lx = sp->v0[0] - ox, ly = sp->v0[1] - oy, lz = sp->v0[2] - oz;       // :54
+    const float tca = dot_zero_first(lx, ly, lz, dx, dy, dz);                        // :55
+    const bool behind = tca < 0.0f;                                                  // :56-58
+    const float d2 = dot_zero_first(lx, ly, lz, lx, ly, lz) - tca * tca;             // :59
+    const bool outside = d2 > radius2;                                               // :60-62
+    const float thc = sqrtf(radius2 - d2);                                           // :64
+    float t0 = tca - thc, t1 = tca + thc;                                            // :66-67
+    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }                        // :69-71
+    bool both_behind = false;
+    if (t0 < 0.0f) {                                                                 // :74-79
+        t0 = t1;
+        both_behind = t0 < 0.0f;
+    }
+    const float px = ox + t0 * dx, py = oy + t0 * dy, pz = oz + t0 * dz;             // :81
+    const float qx = px - ox, qy = py - oy, qz = pz - oz;                            // distance(p_hit, origin) = norm(p_hit - origin), :82
+    t = sqrtf(dot_zero_first(qx, qy, qz, qx, qy, qz));
+    return !behind && !outside && !both_behind;
+}
+
 // The literal reference traversal, for wavefronts that hold a ray with a zero / denormal / non-finite
 // direction component.  For such rays BoundingBox::intersect produces +-inf and NaN (0/0) terms and
 // the outcome depends on the tree: e.g. with d.y = -0.0 an ancestor box gives tymin=+inf, tymax=-inf
@@ -158,7 +194,7 @@ __device__ __forceinline__ bool direction_is_hard(float dx, float dy, float dz)
 // "take when t <= best" is the fold of its "left only if strictly less" rule (:123-130).
 // When the reference tree was not built (RTX_REFTREE_NEVER / too many primitives) the same walk runs
 // on the library's tree, with ties by rank.
-template <bool COUNT>
+template <bool COUNT, bool SPHERES = false>
 __device__ __forceinline__ void closest_hit_reference(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                                     const TriRec RTX_CONSTANT *__restrict__ tris,
                                                     const ShadeRec *__restrict__ shade, uint32_t n_nodes,
@@ -183,24 +219,32 @@ __device__ __forceinline__ void closest_hit_reference(const NodeRec RTX_CONSTANT
         const bool any = __ballot(pass) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
         if (leaf && any) {
-            const uint32_t first = cur.info & ~kLeafFlag;
+            const uint32_t first = cur.info & kLeafIndexMask;
+            const bool spheres = SPHERES && (cur.info & kSphereFlag) != 0u;
             for (uint32_t k = 0; k < cur.link; ++k) {
                 const TriRec RTX_CONSTANT *tr = tris + (first + k);
-                const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
-                const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
                 if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
-                const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
-                const float det = e1x * pvx + e1y * pvy + e1z * pvz;
-                const bool parallel = det < 0.00001f && det > -0.00001f;
-                const float inv = 1.0f / det;
-                const float tvx = ox - tr->v0[0], tvy = oy - tr->v0[1], tvz = oz - tr->v0[2];
-                const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;
-                const bool out_u = u < 0.0f || u > 1.0f;
-                const float qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;
-                const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;
-                const bool out_v = v < 0.0f || u + v > 1.0f;
-                const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;
-                if (pass && !parallel && !out_u && !out_v && !(t < 1.0f)) {
+                float t;
+                bool some;
+                if (spheres) {
+                    some = sphere_distance(tr, ox, oy, oz, dx, dy, dz, t);
+                } else {
+                    const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
+                    const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
+                    const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+                    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                    const bool parallel = det < 0.00001f && det > -0.00001f;
+                    const float inv = 1.0f / det;
+                    const float tvx = ox - tr->v0[0], tvy = oy - tr->v0[1], tvz = oz - tr->v0[2];
+                    const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;
+                    const bool out_u = u < 0.0f || u > 1.0f;
+                    const float qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;
+                    const float v = (dx * qvx + dy * qvy + dz * qvz) * inv;
+                    const bool out_v = v < 0.0f || u + v > 1.0f;
+                    t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;
+                    some = !parallel && !out_u && !out_v;
+                }
+                if (pass && some && !(t < 1.0f)) {
                     // multi-triangle leaves (library tree): the triangle's own box still gates it; on the
                     // reference stream the leaf box is this box and the test repeats with the same result
                     if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
@@ -316,12 +360,39 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
     }
 }
 
+// The spheres of one leaf against the ray of every lane: Sphere::intersect, then the same leaf rule, leaf box and
+// tie rule as a triangle (BVHNode::intersect does not look at the arm, bvh.rs:50-86).
+template <bool COUNT>
+__device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restrict__ tris,
+                                             const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
+                                             LaneRay &r, unsigned long long n_active, WaveCounters &wc)
+{
+    for (uint32_t k = 0; k < count; ++k) {
+        const TriRec RTX_CONSTANT *sp = tris + (first + k);
+        if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+        float t;
+        const bool some = sphere_distance(sp, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t);
+        if (r.active && some && !(t < 1.0f)) {
+            if (slab_exact(sp->bmin[0], sp->bmin[1], sp->bmin[2], sp->bmax[0], sp->bmax[1], sp->bmax[2],
+                           r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) {
+                const uint32_t idx = sp->idx;
+                bool take = t < r.best_t;
+                if (!take && t == r.best_t && r.best_idx != kNone)
+                    take = shade[idx].rank > shade[r.best_idx].rank;
+                if (take) { r.best_t = t; r.best_idx = idx; }
+            }
+        }
+    }
+}
+
 // One wave-uniform closest-hit traversal over the library's stream.
 // Valid for rays whose direction components are regular or soft (see the classes above): then the result
 // does not depend on the tree.  Returns false (and traces nothing) when an active lane's direction is hard:
 // the tile is then re-rendered by reference_tiles_kernel.  A wavefront holding a soft direction uses the
 // exact slab test for this traversal (the multiply-based culling needs finite 1/d).
-template <bool COUNT, bool FAST>
+// SPHERES = false compiles the Sphere arm out: scenes without spheres (every BASELINE configuration) run the
+// triangle-only kernel, whose register allocation the extra arm would otherwise push into scratch.
+template <bool COUNT, bool FAST, bool SPHERES = false>
 __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
@@ -337,7 +408,10 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
         const bool leaf = (cur.info & kLeafFlag) != 0u;
         const bool any = __ballot(r.active && box_pass(use_fast, cur, r)) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
-        if (leaf && any) leaf_triangles<COUNT>(tris, shade, cur.info & ~kLeafFlag, cur.link, r, n_active, wc);
+        if (leaf && any) {
+            if (SPHERES && (cur.info & kSphereFlag)) leaf_spheres<COUNT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
+            else leaf_triangles<COUNT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
+        }
         // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
         i = (any || leaf) ? i + 1u : cur.link;
     }

@@ -141,6 +141,20 @@ int build_gamma_thresholds(float thr[256])
 int ref_tree_build(uint32_t n, const float *v0v1v2, uint32_t *out_rank, std::vector<NodeRec> *out_stream)
 {
     if (!n || !v0v1v2) return RTX_ERR_BAD_ARG;
+    std::vector<float> boxes(6 * static_cast<size_t>(n));
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *t = v0v1v2 + 9 * static_cast<size_t>(i);
+        for (int k = 0; k < 3; ++k) {                     // Triangle::get_bounding_box, triangle.rs:45-56
+            boxes[6 * static_cast<size_t>(i) + k] = lesser(lesser(t[k], t[3 + k]), t[6 + k]);
+            boxes[6 * static_cast<size_t>(i) + 3 + k] = greater(greater(t[k], t[3 + k]), t[6 + k]);
+        }
+    }
+    return ref_tree_build_boxes(n, boxes.data(), out_rank, out_stream);
+}
+
+int ref_tree_build_boxes(uint32_t n, const float *lo_hi, uint32_t *out_rank, std::vector<NodeRec> *out_stream)
+{
+    if (!n || !lo_hi) return RTX_ERR_BAD_ARG;
     struct Cluster { float lo[3], hi[3]; int32_t left, right; };   // left < 0: leaf
     std::vector<Cluster> pool;
     pool.reserve(2 * static_cast<size_t>(n));
@@ -151,12 +165,9 @@ int ref_tree_build(uint32_t n, const float *v0v1v2, uint32_t *out_rank, std::vec
     };
     std::vector<int32_t> level(n), next;
     for (uint32_t i = 0; i < n; ++i) {
-        const float *t = v0v1v2 + 9 * static_cast<size_t>(i);
         Cluster c;
-        for (int k = 0; k < 3; ++k) {
-            c.lo[k] = lesser(lesser(t[k], t[3 + k]), t[6 + k]);
-            c.hi[k] = greater(greater(t[k], t[3 + k]), t[6 + k]);
-        }
+        std::memcpy(c.lo, lo_hi + 6 * static_cast<size_t>(i), 12);
+        std::memcpy(c.hi, lo_hi + 6 * static_cast<size_t>(i) + 3, 12);
         c.left = -1;
         c.right = static_cast<int32_t>(i);   // leaf: right holds the primitive index
         pool.push_back(c);
@@ -250,6 +261,7 @@ struct Prim {
     float lo[3], hi[3];
     float c[3];
     uint32_t idx;
+    uint32_t kind;   // 0 triangle, 1 sphere
 };
 
 struct Box {
@@ -304,8 +316,13 @@ public:
             mid = begin + count / 2;
             split = true;
         }
+        if (!split) {                             // a leaf holds one arm of Primitive: split a mixed range by arm
+            auto it = std::partition(prims_.begin() + begin, prims_.begin() + end, [](const Prim &p) { return p.kind == 0u; });
+            mid = static_cast<uint32_t>(it - prims_.begin());
+            split = mid > begin && mid < end;
+        }
         if (!split) {
-            nodes_[self].info = kLeafFlag | begin;
+            nodes_[self].info = kLeafFlag | (prims_[begin].kind ? kSphereFlag : 0u) | begin;
             nodes_[self].link = count;
             ++leaves;
             if (count > max_leaf) max_leaf = count;
@@ -387,10 +404,17 @@ private:
 
 int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
 {
-    if (!d.width || !d.height || !d.n_tris || !d.v0v1v2 || !d.rgb || !d.samples || !d.n_samples || !d.nb_ray)
-        return RTX_ERR_BAD_ARG;
-    if (d.n_tris >= 0x40000000u || d.accel > RTX_ACCEL_BRUTE || d.reference_tree > RTX_REFTREE_NEVER) return RTX_ERR_BAD_ARG;
+    const uint64_t n_prims64 = static_cast<uint64_t>(d.n_tris) + d.n_spheres;
+    if (!d.width || !d.height || !n_prims64 || !d.samples || !d.n_samples || !d.nb_ray) return RTX_ERR_BAD_ARG;
+    if ((d.n_tris && (!d.v0v1v2 || !d.rgb)) || (d.n_spheres && (!d.spheres || !d.sphere_rgb))) return RTX_ERR_BAD_ARG;
+    if (n_prims64 > kLeafIndexMask || d.accel > RTX_ACCEL_BRUTE || d.reference_tree > RTX_REFTREE_NEVER) return RTX_ERR_BAD_ARG;
     if (static_cast<uint64_t>(d.width) * d.height >= (1ull << 31)) return RTX_ERR_BAD_ARG;
+    const uint32_t n_prims = static_cast<uint32_t>(n_prims64);
+    if (d.kinds) {
+        uint64_t ones = 0;
+        for (uint32_t i = 0; i < n_prims; ++i) ones += d.kinds[i] != 0;
+        if (ones != d.n_spheres) return RTX_ERR_BAD_ARG;
+    }
 
     s.width = d.width;
     s.height = d.height;
@@ -401,7 +425,8 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
     s.distance = d.distance;
     s.nb_ray = d.nb_ray;
     s.nb_light_sample = d.nb_light_sample;
-    s.n_tris = d.n_tris;
+    s.n_tris = n_prims;
+    s.n_spheres = d.n_spheres;
     s.n_samples = d.n_samples;
     try {
         s.samples.assign(d.samples, d.samples + 2 * static_cast<size_t>(d.n_samples));
@@ -419,32 +444,46 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
         const int grc = build_gamma_thresholds(s.gamma_thr);
         if (grc != RTX_OK) return grc;
 
-        // the reference's own tree (see ref_tree_build): ranks for exact ties, stream for irregular rays
-        std::vector<uint32_t> ref_rank;
-        s.ref_nodes.clear();
-        const bool want_ref = d.reference_tree == RTX_REFTREE_ALWAYS ||
-                              (d.reference_tree == RTX_REFTREE_AUTO && d.n_tris <= kRefTreeAutoMax);
-        if (want_ref) {
-            ref_rank.resize(d.n_tris);
-            const int rrc = ref_tree_build(d.n_tris, d.v0v1v2, ref_rank.data(), &s.ref_nodes);
-            if (rrc != RTX_OK) return rrc;
-        }
-
-        std::vector<Prim> prims(d.n_tris);
-        std::vector<TriRec> recs(d.n_tris);   // caller order for now
-        s.shade.resize(d.n_tris);
-        for (uint32_t i = 0; i < d.n_tris; ++i) {
-            const float *t = d.v0v1v2 + 9 * static_cast<size_t>(i);
-            for (int k = 0; k < 9; ++k)
-                if (!std::isfinite(t[k])) return RTX_ERR_UNSUPPORTED;
+        // primitive records in the order of the caller's Vec<Primitive> (kinds), both arms
+        std::vector<Prim> prims(n_prims);
+        std::vector<TriRec> recs(n_prims);
+        std::vector<float> boxes(6 * static_cast<size_t>(n_prims));
+        s.shade.resize(n_prims);
+        uint32_t next_tri = 0, next_sphere = 0;
+        for (uint32_t i = 0; i < n_prims; ++i) {
+            const bool sphere = d.kinds ? d.kinds[i] != 0 : i >= d.n_tris;
             TriRec &r = recs[i];
             ShadeRec &sh = s.shade[i];
-            std::memcpy(r.v0, t, 12);
-            triangle_derive(t, t + 3, t + 6, r.e1, r.e2, sh.normal, r.bmin, r.bmax);
+            std::memset(&r, 0, sizeof r);
+            if (sphere) {
+                const float *p = d.spheres + 4 * static_cast<size_t>(next_sphere);
+                for (int k = 0; k < 4; ++k)
+                    if (!std::isfinite(p[k])) return RTX_ERR_UNSUPPORTED;
+                const float radius = p[3];
+                std::memcpy(r.v0, p, 12);
+                r.e1[0] = radius * radius;                                   // Sphere::new, sphere.rs:26
+                r.e1[1] = radius;
+                for (int k = 0; k < 3; ++k) {                                // get_bounding_box, sphere.rs:32-41
+                    r.bmin[k] = p[k] - radius;
+                    r.bmax[k] = p[k] + radius;
+                }
+                std::memcpy(sh.normal, p, 12);                               // the origin; get_normal needs p_hit (sphere.rs:93-95)
+                std::memcpy(sh.rgb, d.sphere_rgb + 3 * static_cast<size_t>(next_sphere), 12);
+                sh.kind = 1;
+                ++next_sphere;
+            } else {
+                const float *t = d.v0v1v2 + 9 * static_cast<size_t>(next_tri);
+                for (int k = 0; k < 9; ++k)
+                    if (!std::isfinite(t[k])) return RTX_ERR_UNSUPPORTED;
+                std::memcpy(r.v0, t, 12);
+                triangle_derive(t, t + 3, t + 6, r.e1, r.e2, sh.normal, r.bmin, r.bmax);
+                std::memcpy(sh.rgb, d.rgb + 3 * static_cast<size_t>(next_tri), 12);
+                sh.kind = 0;
+                ++next_tri;
+            }
             r.idx = i;
-            std::memcpy(sh.rgb, d.rgb + 3 * static_cast<size_t>(i), 12);
-            sh.rank = d.tie_rank ? d.tie_rank[i] : (want_ref ? ref_rank[i] : i);
-            sh.pad = 0;
+            std::memcpy(&boxes[6 * static_cast<size_t>(i)], r.bmin, 12);
+            std::memcpy(&boxes[6 * static_cast<size_t>(i) + 3], r.bmax, 12);
             Prim &p = prims[i];
             for (int k = 0; k < 3; ++k) {
                 p.lo[k] = r.bmin[k];
@@ -452,42 +491,81 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                 p.c[k] = 0.5f * r.bmin[k] + 0.5f * r.bmax[k];
             }
             p.idx = i;
+            p.kind = sphere ? 1u : 0u;
         }
 
+        // the reference's own tree (see ref_tree_build): ranks for exact ties, stream for hard directions
+        std::vector<uint32_t> ref_rank;
+        s.ref_nodes.clear();
+        const bool want_ref = d.reference_tree == RTX_REFTREE_ALWAYS ||
+                              (d.reference_tree == RTX_REFTREE_AUTO && n_prims <= kRefTreeAutoMax);
+        if (want_ref) {
+            ref_rank.resize(n_prims);
+            const int rrc = ref_tree_build_boxes(n_prims, boxes.data(), ref_rank.data(), &s.ref_nodes);
+            if (rrc != RTX_OK) return rrc;
+        }
+        for (uint32_t i = 0; i < n_prims; ++i)
+            s.shade[i].rank = d.tie_rank ? d.tie_rank[i] : (want_ref ? ref_rank[i] : i);
+
         s.nodes.clear();
-        s.nodes.reserve(2 * static_cast<size_t>(d.n_tris));
+        s.nodes.reserve(2 * static_cast<size_t>(n_prims));
         if (d.accel == RTX_ACCEL_BRUTE) {
-            Box all;
-            all.reset();
-            for (const Prim &p : prims) all.grow(p.lo, p.hi);
-            NodeRec rec;
-            std::memcpy(rec.bmin, all.lo, 12);
-            std::memcpy(rec.bmax, all.hi, 12);
-            rec.info = kLeafFlag | 0u;
-            rec.link = d.n_tris;
-            s.nodes.push_back(rec);
-            s.n_leaves = 1;
-            s.max_leaf_tris = d.n_tris;
-            s.depth = 1;
+            // one leaf per arm (a leaf holds one arm only), under a root when both are present
+            auto it = std::stable_partition(prims.begin(), prims.end(), [](const Prim &p) { return p.kind == 0u; });
+            const uint32_t n_tri_prims = static_cast<uint32_t>(it - prims.begin());
+            auto leaf_of = [&](uint32_t begin, uint32_t end) {
+                Box b;
+                b.reset();
+                for (uint32_t i = begin; i < end; ++i) b.grow(prims[i].lo, prims[i].hi);
+                NodeRec rec;
+                std::memcpy(rec.bmin, b.lo, 12);
+                std::memcpy(rec.bmax, b.hi, 12);
+                rec.info = kLeafFlag | (prims[begin].kind ? kSphereFlag : 0u) | begin;
+                rec.link = end - begin;
+                return rec;
+            };
+            if (n_tri_prims == 0 || n_tri_prims == n_prims) {
+                s.nodes.push_back(leaf_of(0, n_prims));
+            } else {
+                const NodeRec a = leaf_of(0, n_tri_prims), b = leaf_of(n_tri_prims, n_prims);
+                Box all;
+                all.reset();
+                all.grow(a.bmin, a.bmax);
+                all.grow(b.bmin, b.bmax);
+                NodeRec root;
+                std::memcpy(root.bmin, all.lo, 12);
+                std::memcpy(root.bmax, all.hi, 12);
+                root.info = 0;
+                root.link = 3;
+                s.nodes.push_back(root);
+                s.nodes.push_back(a);
+                s.nodes.push_back(b);
+            }
+            s.n_leaves = static_cast<uint32_t>(s.nodes.size() == 1 ? 1 : 2);
+            s.max_leaf_tris = std::max(n_tri_prims, n_prims - n_tri_prims);
+            s.depth = s.nodes.size() == 1 ? 1 : 2;
         } else {
             uint32_t leaf_max = d.leaf_max ? d.leaf_max : 4;
             double box_cost = 1.0;
             if (const char *e = std::getenv("RTX_LEAF_MAX")) leaf_max = std::max(1, std::atoi(e));
             if (const char *e = std::getenv("RTX_SAH_BOX_COST")) box_cost = std::atof(e);
             TreeBuilder tb(prims, s.nodes, leaf_max, box_cost);
-            tb.build(0, d.n_tris, 0);
+            tb.build(0, n_prims, 0);
             s.n_leaves = tb.leaves;
             s.max_leaf_tris = tb.max_leaf;
             s.depth = tb.depth;
         }
-        s.tris.resize(d.n_tris);
-        std::vector<uint32_t> pos_of(d.n_tris);
-        for (uint32_t i = 0; i < d.n_tris; ++i) {
+        s.tris.resize(n_prims);
+        std::vector<uint32_t> pos_of(n_prims);
+        for (uint32_t i = 0; i < n_prims; ++i) {
             s.tris[i] = recs[prims[i].idx];
             pos_of[prims[i].idx] = i;
         }
-        for (NodeRec &nd : s.ref_nodes)   // leaves of the reference stream point at the same TriRec array
-            if (nd.info & kLeafFlag) nd.info = kLeafFlag | pos_of[nd.info & ~kLeafFlag];
+        for (NodeRec &nd : s.ref_nodes)   // leaves of the reference stream point at the same record array
+            if (nd.info & kLeafFlag) {
+                const uint32_t prim = nd.info & kLeafIndexMask;
+                nd.info = kLeafFlag | (s.shade[prim].kind ? kSphereFlag : 0u) | pos_of[prim];
+            }
     } catch (const std::bad_alloc &) {
         return RTX_ERR_OOM;
     }

@@ -18,7 +18,10 @@ namespace rtx {
 // by the kernel with one scalar 32-byte load.
 //   inner node : info = 0,            link = index of the node to continue with when the
 //                                     subtree is skipped (its first child is at index+1)
-//   leaf  node : info = 0x80000000|s, link = number of triangle records, s = first record
+//   leaf  node : info = 0x80000000|s, link = number of primitive records, s = first record;
+//                bit 30 (kSphereFlag) set when the records are spheres — a leaf holds one arm of
+//                Primitive only (src/tracer/primitives/mod.rs:40-43), so the kernel's dispatch on
+//                the arm is a scalar branch per leaf
 struct NodeRec {
     float    bmin[3];
     uint32_t link;
@@ -27,11 +30,15 @@ struct NodeRec {
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
 constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kSphereFlag = 0x40000000u;
+constexpr uint32_t kLeafIndexMask = 0x3FFFFFFFu;
 
 // One triangle as the traversal consumes it: 16 dwords, one scalar 64-byte load.
 // v0,e1,e2 are the 36 bytes Möller–Trumbore reads (triangle.rs:66-94); bmin/bmax are the
 // triangle's own AABB (triangle.rs:45-56), needed because the reference only counts a leaf
 // whose box test passed (bounding_volume_hierarchy.rs:52); idx = index in the caller's order.
+// A Sphere (sphere.rs:12-18) uses the same 64-byte slot: v0 = origin, e1[0] = radius2 (sphere.rs:26),
+// e1[1] = radius, bmin/bmax = origin -+ radius (sphere.rs:32-41); the leaf's kSphereFlag says which.
 struct TriRec {
     float    v0[3];
     float    e1[3];
@@ -42,12 +49,12 @@ struct TriRec {
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
-// Shading data of a triangle, indexed by the caller's triangle index (read once per hit).
+// Shading data of a primitive, indexed by its position in the caller's Vec<Primitive> (read once per hit).
 struct ShadeRec {
-    float    normal[3];   // Triangle::new, triangle.rs:29
+    float    normal[3];   // triangle: Triangle::new, triangle.rs:29; sphere: its origin (normal = normalize(p_hit - origin), sphere.rs:93-95)
     uint32_t rank;        // tie rank (see RtxSceneDesc.tie_rank)
     float    rgb[3];      // Color
-    uint32_t pad;
+    uint32_t kind;        // 0 triangle, 1 sphere
 };
 static_assert(sizeof(ShadeRec) == 32, "ShadeRec must be 32 bytes");
 
@@ -56,11 +63,12 @@ struct PreparedScene {
     float eye[3], cam_u[3], cam_v[3], cam_w[3];
     float distance = 0;
     uint32_t nb_ray = 1, nb_light_sample = 0;
-    uint32_t n_tris = 0;
+    uint32_t n_tris = 0;               // primitives in the Vec (both arms)
+    uint32_t n_spheres = 0;            // of which spheres
     uint32_t n_samples = 0;
     std::vector<NodeRec>  nodes;
     std::vector<NodeRec>  ref_nodes;   // the reference's own tree as a stream (empty when not built)
-    std::vector<TriRec>   tris;        // in leaf order
+    std::vector<TriRec>   tris;        // primitive records (triangles and spheres) in leaf order
     std::vector<ShadeRec> shade;       // in caller order
     std::vector<float>    samples;     // n_samples x 2
     std::vector<float>    light_points;// nb_ray x nb_light_sample x 3
@@ -82,6 +90,8 @@ uint8_t gamma_quantise(float linear);
 int  build_gamma_thresholds(float thr[256]);
 int  ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank);
 int  ref_tree_build(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank, std::vector<NodeRec> *out_stream);
+// same over the primitives' own boxes (n x {min xyz, max xyz}) — what the reference clusters by, whatever the arm
+int  ref_tree_build_boxes(uint32_t n, const float *lo_hi, uint32_t *out_rank, std::vector<NodeRec> *out_stream);
 // above this many primitives RTX_REFTREE_AUTO skips the O(n^2) reference tree (the reference itself could not build it)
 constexpr uint32_t kRefTreeAutoMax = 50000u;
 

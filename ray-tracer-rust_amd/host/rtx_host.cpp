@@ -7,7 +7,8 @@
 // Differences, all explicit: the sample table is seeded (the reference uses thread_rng), every
 // pixel is rendered (the reference drops len % (num_cpus-1) pixels), timing is in milliseconds
 // and the throughput counts all rays (the reference prints integer seconds and primary rays only,
-// src/main.rs:305-310).  Options exist because the reference hard-codes what they set.
+// src/main.rs:305-310).  Options exist because the reference hard-codes what they set;
+// --random-spheres / --random-triangles add the primitives of the reference's (unused) generators.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,7 @@ int main(int argc, char **argv)
 {
     uint32_t width = 1920, height = 1080, tile_rows = 8;
     uint64_t seed = 20261004ull;
+    bool random_spheres = false, random_triangles = false;
     std::string out = "output.png";
     std::vector<int> devices;
     std::vector<std::string> objs;
@@ -37,6 +39,8 @@ int main(int argc, char **argv)
         else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 10);
         else if (a == "--out") out = next("--out");
         else if (a == "--tile-rows") tile_rows = static_cast<uint32_t>(std::atoi(next("--tile-rows")));
+        else if (a == "--random-spheres") random_spheres = true;        // gen_random_spheres, main.rs:42-67
+        else if (a == "--random-triangles") random_triangles = true;    // gen_random_triangles, main.rs:69-99
         else if (a == "--devices") {
             for (char *tok = std::strtok(const_cast<char *>(next("--devices")), ","); tok; tok = std::strtok(nullptr, ","))
                 devices.push_back(std::atoi(tok));
@@ -53,6 +57,8 @@ int main(int argc, char **argv)
         if (err != RTX_OK) std::printf("Not a valid path: %s\n", path.c_str());   // main.rs:118
         prims.insert(prims.end(), mesh.begin(), mesh.end());
     }
+    if (random_spheres) { const auto sp = gen_random_spheres(seed ^ 0x5eedull); prims.insert(prims.end(), sp.begin(), sp.end()); }
+    if (random_triangles) { const auto tr = gen_random_triangles(seed ^ 0x7717ull); prims.insert(prims.end(), tr.begin(), tr.end()); }
     prims.insert(prims.end(), ground.begin(), ground.end());                  // main.rs:335
 
     primitives::Light area_light{{primitives::Triangle::create({-10.0f, 300.0f, -10.0f}, {10.0f, 300.0f, -10.0f},

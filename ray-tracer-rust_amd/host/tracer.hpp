@@ -8,7 +8,7 @@
 //   tracer::utils::Color                  src/tracer/utils/color.rs:4-26
 //   tracer::utils::Camera                 src/tracer/utils/camera.rs:5-35      (Camera::create = Camera::new)
 //   tracer::primitives::Triangle          src/tracer/primitives/triangle.rs:11-34
-//   tracer::primitives::Sphere            src/tracer/primitives/sphere.rs:12-29 (carried; not traced yet)
+//   tracer::primitives::Sphere            src/tracer/primitives/sphere.rs:12-29
 //   tracer::primitives::Primitive         src/tracer/primitives/mod.rs:40-43   (enum -> std::variant)
 //   tracer::primitives::Light             src/tracer/primitives/light.rs:6-8
 //   tracer::utils::BoundingVolumeHierarchy  src/tracer/utils/bounding_volume_hierarchy.rs:145-148,173
@@ -16,6 +16,8 @@
 //   tracer::render(scene, ...)            src/main.rs:242-317 (the dispatcher; the thread fan-out
 //                                         :275-303 becomes row tiles over GPUs)
 //   tracer::import_obj / create_ground    src/main.rs:114-149 / :102-111
+//   tracer::gen_random_spheres / gen_random_triangles   src/main.rs:42-67 / :69-99 (dead code in the reference;
+//                                         seeded here, the reference draws from thread_rng)
 //
 // Header-only; link against librtx.so.
 #pragma once
@@ -108,23 +110,37 @@ public:
     {
         BoundingVolumeHierarchy b;
         int rc = RTX_OK;
-        for (const auto &p : prims) {
-            const auto *t = std::get_if<primitives::Triangle>(&p);
-            if (!t) { rc = RTX_ERR_UNSUPPORTED; break; }   // Sphere arm: not on the GPU path yet
-            const float v[9] = {t->v0.x, t->v0.y, t->v0.z, t->v1.x, t->v1.y, t->v1.z, t->v2.x, t->v2.y, t->v2.z};
-            b.v0v1v2_.insert(b.v0v1v2_.end(), v, v + 9);
-            const float c[3] = {t->color.red, t->color.green, t->color.blue};
-            b.rgb_.insert(b.rgb_.end(), c, c + 3);
+        for (const auto &p : prims) {             // both arms, in the order of the Vec (kinds_)
+            if (const auto *t = std::get_if<primitives::Triangle>(&p)) {
+                const float v[9] = {t->v0.x, t->v0.y, t->v0.z, t->v1.x, t->v1.y, t->v1.z, t->v2.x, t->v2.y, t->v2.z};
+                b.v0v1v2_.insert(b.v0v1v2_.end(), v, v + 9);
+                const float c[3] = {t->color.red, t->color.green, t->color.blue};
+                b.rgb_.insert(b.rgb_.end(), c, c + 3);
+                b.kinds_.push_back(0);
+            } else {
+                const auto &sp = std::get<primitives::Sphere>(p);
+                const float v[4] = {sp.origin.x, sp.origin.y, sp.origin.z, sp.radius};
+                b.spheres_.insert(b.spheres_.end(), v, v + 4);
+                const float c[3] = {sp.color.red, sp.color.green, sp.color.blue};
+                b.sphere_rgb_.insert(b.sphere_rgb_.end(), c, c + 3);
+                b.kinds_.push_back(1);
+            }
         }
         if (err) *err = rc;
         return b;
     }
-    uint32_t len() const { return static_cast<uint32_t>(rgb_.size() / 3); }
+    uint32_t len() const { return static_cast<uint32_t>(kinds_.size()); }
+    uint32_t n_triangles() const { return static_cast<uint32_t>(rgb_.size() / 3); }
+    uint32_t n_spheres() const { return static_cast<uint32_t>(sphere_rgb_.size() / 3); }
     const float *vertices() const { return v0v1v2_.data(); }
     const float *colors() const { return rgb_.data(); }
+    const float *spheres() const { return spheres_.data(); }
+    const float *sphere_colors() const { return sphere_rgb_.data(); }
+    const uint8_t *kinds() const { return kinds_.data(); }
 
 private:
-    std::vector<float> v0v1v2_, rgb_;
+    std::vector<float> v0v1v2_, rgb_, spheres_, sphere_rgb_;
+    std::vector<uint8_t> kinds_;
 };
 
 struct Scene {
@@ -159,6 +175,32 @@ inline std::vector<primitives::Primitive> import_obj(const std::string &path, in
     return out;
 }
 
+// gen_random_spheres — src/main.rs:42-67: one sphere, radius in [400, 500), at (0, 0, -1000), random colour.
+// gen_random_triangles — src/main.rs:69-99: ten triangles, x and y in [-500, 500), z in [-100, -50), random colour.
+// The reference draws from thread_rng; the stand-in is the library's seeded generator, values taken in the
+// reference's call order (Range::ind_sample = low + (high - low) * u).
+inline std::vector<primitives::Primitive> gen_random_spheres(uint64_t seed)
+{
+    float u[4];
+    rtxh_gen_samples(seed, 2, u);
+    return {primitives::Sphere::create(400.0f + 100.0f * u[0], {0.0f, 0.0f, -1000.0f}, utils::Color::create(u[1], u[2], u[3]))};
+}
+
+inline std::vector<primitives::Primitive> gen_random_triangles(uint64_t seed)
+{
+    std::vector<primitives::Primitive> out;
+    float u[10 * 12];
+    rtxh_gen_samples(seed, 10 * 6, u);
+    for (int i = 0; i < 10; ++i) {
+        const float *p = u + 12 * i;
+        auto xy = [](float a) { return -500.0f + 1000.0f * a; };
+        auto z = [](float a) { return -100.0f + 50.0f * a; };
+        out.emplace_back(primitives::Triangle::create({xy(p[0]), xy(p[1]), z(p[2])}, {xy(p[3]), xy(p[4]), z(p[5])},
+                                                      {xy(p[6]), xy(p[7]), z(p[8])}, utils::Color::create(p[9], p[10], p[11])));
+    }
+    return out;
+}
+
 // The seeded stand-in for the table render() fills from thread_rng (src/main.rs:253,260-265)
 inline std::vector<std::pair<float, float>> random_samples(uint64_t seed, uint32_t n = NB_RAND_SAMPLE)
 {
@@ -188,9 +230,13 @@ inline int render(const utils::Scene &scene, const std::vector<std::pair<float, 
     const float l0[3] = {lt->v0.x, lt->v0.y, lt->v0.z}, l1[3] = {lt->v1.x, lt->v1.y, lt->v1.z},
                 l2[3] = {lt->v2.x, lt->v2.y, lt->v2.z};
     for (int k = 0; k < 3; ++k) { d.light_v0[k] = l0[k]; d.light_v1[k] = l1[k]; d.light_v2[k] = l2[k]; }
-    d.n_tris = scene.bvh.len();
+    d.n_tris = scene.bvh.n_triangles();
     d.v0v1v2 = scene.bvh.vertices();
     d.rgb = scene.bvh.colors();
+    d.n_spheres = scene.bvh.n_spheres();
+    d.spheres = scene.bvh.spheres();
+    d.sphere_rgb = scene.bvh.sphere_colors();
+    d.kinds = scene.bvh.kinds();
     d.tie_rank = nullptr;                    // taken from the reference tree the library rebuilds
     d.reference_tree = RTX_REFTREE_AUTO;
     d.nb_ray = nb_ray;

@@ -58,6 +58,7 @@ class SceneDesc(C.Structure):
         ("nb_ray", C.c_uint32), ("nb_light_sample", C.c_uint32),
         ("samples", f32p), ("n_samples", C.c_uint32),
         ("accel", C.c_uint32), ("leaf_max", C.c_uint32), ("reference_tree", C.c_uint32),
+        ("n_spheres", C.c_uint32), ("spheres", f32p), ("sphere_rgb", f32p), ("kinds", u8p),
     ]
 
 
@@ -222,7 +223,11 @@ class Scene:
     def __init__(self, width, height, tris, rgb, samples, *, eye=DEFAULT_EYE, look_at=DEFAULT_LOOK_AT,
                  up=DEFAULT_UP, distance=DEFAULT_DISTANCE, light_tri=DEFAULT_LIGHT, nb_ray=NB_RAY,
                  nb_light_sample=NB_LIGHT_SAMPLE, accel=ACCEL_BVH, leaf_max=0, tie_rank="reference",
-                 reference_tree=REFTREE_AUTO):
+                 reference_tree=REFTREE_AUTO, spheres=None, sphere_rgb=None, kinds=None):
+        """spheres [m, 4] (origin x, y, z, radius) and sphere_rgb [m, 3] are the Sphere arm of Primitive
+        (src/tracer/primitives/sphere.rs:12-29); kinds (uint8 per primitive, 0 = next triangle, 1 = next sphere)
+        gives the order of the Vec<Primitive>, default all triangles then all spheres.  tie_rank, when given,
+        is indexed by position in that Vec."""
         self._h = C.c_void_p()
         self.width, self.height = int(width), int(height)
         self.tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
@@ -230,6 +235,16 @@ class Scene:
         self.samples = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, 2)
         if len(self.rgb) != len(self.tris):
             raise ValueError("rgb and tris disagree")
+        self.spheres = np.zeros((0, 4), np.float32) if spheres is None else \
+            np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+        self.sphere_rgb = np.ones((len(self.spheres), 3), np.float32) if sphere_rgb is None else \
+            np.ascontiguousarray(sphere_rgb, dtype=np.float32).reshape(-1, 3)
+        if len(self.sphere_rgb) != len(self.spheres):
+            raise ValueError("sphere_rgb and spheres disagree")
+        self.kinds = None if kinds is None else np.ascontiguousarray(kinds, dtype=np.uint8).reshape(-1)
+        if self.kinds is not None and len(self.kinds) != len(self.tris) + len(self.spheres):
+            raise ValueError("kinds must have one entry per primitive")
+        self.n_prims = len(self.tris) + len(self.spheres)
         if isinstance(tie_rank, str):
             if tie_rank != "reference":
                 raise ValueError(tie_rank)
@@ -249,6 +264,13 @@ class Scene:
         d.light_v0[:], d.light_v1[:], d.light_v2[:] = lt[0:3].tolist(), lt[3:6].tolist(), lt[6:9].tolist()
         d.n_tris = len(self.tris)
         d.v0v1v2, d.rgb = _fp(self.tris), _fp(self.rgb)
+        d.n_spheres = len(self.spheres)
+        if len(self.spheres):
+            d.spheres, d.sphere_rgb = _fp(self.spheres), _fp(self.sphere_rgb)
+        if self.kinds is not None:
+            d.kinds = self.kinds.ctypes.data_as(u8p)
+        if rank is not None and len(rank) != self.n_prims:
+            raise ValueError("tie_rank must have one entry per primitive")
         d.tie_rank = rank.ctypes.data_as(u32p) if rank is not None else None
         d.nb_ray, d.nb_light_sample = int(nb_ray), int(nb_light_sample)
         d.samples, d.n_samples = _fp(self.samples), len(self.samples)
@@ -295,7 +317,7 @@ class Scene:
         return out
 
     def normals(self):
-        out = np.zeros((len(self.tris), 3), np.float32)
+        out = np.zeros((self.n_prims, 3), np.float32)      # a sphere's row holds its origin (its normal needs p_hit)
         _check(_lib.rtx_scene_normals(self._h, _fp(out)), "rtx_scene_normals")
         return out
 

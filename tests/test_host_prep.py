@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(rtx):
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert declared <= exported, declared - exported
     assert declared == set(rtx.rtx._SIGS), declared ^ set(rtx.rtx._SIGS)     # the binding covers the whole header
-    assert rtx.abi_version() == 2
+    assert rtx.abi_version() == 3
     assert rtx.device_count() >= 0
 
 
