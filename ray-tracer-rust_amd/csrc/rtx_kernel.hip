@@ -116,7 +116,7 @@ __device__ __forceinline__ void hit_normal(const ShadeRec &sh, float hx, float h
 struct ShadowRay {
     LaneRay ray;
     uint32_t hp, si;
-    float dist_light;
+    bool valid;          // the lane carries a ray (ray.active is consumed by the any-hit walk)
 };
 
 __device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit, const float *__restrict__ l_light,
@@ -131,8 +131,10 @@ __device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit,
     const float *h = l_hit + kHitStride * s.hp;
     const float hx = h[0], hy = h[1], hz = h[2];
     const float vx = l_light[3u * s.si] - hx, vy = l_light[3u * s.si + 1u] - hy, vz = l_light[3u * s.si + 2u] - hz;   // p - orig
-    s.dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                               // main.rs:202
-    s.ray = make_ray(valid, hx, hy, hz, vx / s.dist_light, vy / s.dist_light, vz / s.dist_light);   // main.rs:201
+    const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                     // main.rs:202
+    s.ray = make_ray(valid, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);   // main.rs:201
+    s.ray.limit = dist_light;
+    s.valid = valid;
     return s;
 }
 
@@ -143,13 +145,8 @@ __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, f
     const float *h = l_hit + kHitStride * s.hp;
     const LaneRay &r = s.ray;
     const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
-    bool lit = true;                                                                  // main.rs:229-231
-    if (r.best_idx != kNone) {                                                        // main.rs:219-227
-        const float qx = r.ox - (r.ox + r.best_t * r.dx), qy = r.oy - (r.oy + r.best_t * r.dy),
-                    qz = r.oz - (r.oz + r.best_t * r.dz);
-        lit = sqrtf(qx * qx + qy * qy + qz * qz) > s.dist_light;
-    }
-    if (r.active) l_res[s.hp * res_stride + s.si] = lit ? lnd : kOccluded;
+    const bool lit = r.best_idx == kNone;       // main.rs:219-231 through any_hit: an index is kept only for an occluder
+    if (s.valid) l_res[s.hp * res_stride + s.si] = lit ? lnd : kOccluded;
 }
 
 __device__ __forceinline__ void store_pixel(const DeviceScene &S, uint8_t *__restrict__ out, uint32_t px, uint32_t ly,
@@ -290,7 +287,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 //  slower, 4.3 vs 3.7 ms on C3: it needs ~105 VGPRs, and resident wavefronts hide more latency)
                 for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                     ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
-                    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
+                    const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
                     if (!ok && lane == 0) l_ctl[1] = 1u;
                     shadow_result(l_hit, l_res, res_stride, sr);
                 }
@@ -550,7 +547,8 @@ __global__ void __launch_bounds__(256, COUNT ? 1 : RTX_WAVES_PER_SIMD) shadow_ke
         const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;               // p - orig
         const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                 // main.rs:202
         LaneRay sr = make_ray(valid, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);   // main.rs:201
-        const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, sr, wc);   // main.rs:204
+        sr.limit = dist_light;
+        const bool ok = any_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, sr, wc);   // main.rs:204
         if (!ok) {   // a hard direction in this chunk: queue the tile once for the reference re-render
             if (lane == 0 && (atomicOr(&W.tiles[cd.x].flags, 2u) & 2u) == 0u) {
                 queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = cd.x;
@@ -559,12 +557,7 @@ __global__ void __launch_bounds__(256, COUNT ? 1 : RTX_WAVES_PER_SIMD) shadow_ke
             continue;
         }
         const float lnd = fabsf(h->n[0] * sr.dx + h->n[1] * sr.dy + h->n[2] * sr.dz);   // main.rs:207
-        bool lit = true;                                                              // main.rs:229-231
-        if (sr.best_idx != kNone) {                                                   // main.rs:219-227
-            const float qx = hx - (hx + sr.best_t * sr.dx), qy = hy - (hy + sr.best_t * sr.dy),
-                        qz = hz - (hz + sr.best_t * sr.dz);
-            lit = sqrtf(qx * qx + qy * qy + qz * qz) > dist_light;
-        }
+        const bool lit = sr.best_idx == kNone;                                        // main.rs:219-231 through any_hit
         // results of a tile: [sample][hit pixel] behind the tile's first row: accumulate_kernel reads it coalesced
         if (valid) W.results[(size_t)td.first * S.nb_light + (size_t)si * td.n_hit + hp] = lit ? lnd : kOccluded;
     }

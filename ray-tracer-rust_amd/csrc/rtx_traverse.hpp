@@ -276,7 +276,21 @@ struct LaneRay {
     float best_t;         // minimum accepted distance so far
     uint32_t best_idx;    // caller-order index of its triangle, kNone = no hit
     bool active;          // lanes without a ray never vote
+    float limit;          // any-hit walks only: the distance to the light point (main.rs:202)
 };
+
+// Shadow rays do not need the closest hit.  The reference takes the closest hit t_min and calls the sample lit
+// iff distance(orig, orig + t_min*dir) > dist_light (main.rs:219-231).  f(t) = |orig - fl(orig + fl(t*dir))| is
+// monotone non-decreasing in t >= 0 — every rounding on the way (product, sum, difference, square, sum of
+// squares, square root) is monotone, and each component of the difference keeps its sign — and every candidate
+// has t >= t_min, so   f(t_min) > D   <=>   f(t_c) > D for every candidate c.  A sample is therefore occluded iff
+// SOME accepted candidate fails the test: the lane that finds one stops testing (any-hit), and a wavefront whose
+// lanes have all stopped leaves the walk.  The test on the candidate is the reference's own expression.
+__device__ __forceinline__ bool candidate_occludes(const LaneRay &r, float t)
+{
+    const float qx = r.ox - (r.ox + t * r.dx), qy = r.oy - (r.oy + t * r.dy), qz = r.oz - (r.oz + t * r.dz);   // bvh.rs:69, main.rs:220
+    return !(sqrtf(qx * qx + qy * qy + qz * qz) > r.limit);                                                     // main.rs:221
+}
 
 __device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, float oz, float dx, float dy, float dz)
 {
@@ -291,6 +305,7 @@ __device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, flo
     r.best_t = __builtin_inff();
     r.best_idx = kNone;
     r.active = active;
+    r.limit = __builtin_inff();
     return r;
 }
 
@@ -318,7 +333,7 @@ constexpr bool kTriangleEarlyOut = RTX_TRIANGLE_EARLY_OUT != 0;
 
 // The triangles of one leaf against the ray of every lane: Triangle::intersect (triangle.rs:66-94), the leaf
 // rule x < 1.0 -> None (bvh.rs:64-67), the leaf's own box (bvh.rs:52, exact arithmetic) and the tie rule.
-template <bool COUNT>
+template <bool COUNT, bool ANYHIT = false>
 __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
                                                const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
                                                LaneRay &r, unsigned long long n_active, WaveCounters &wc)
@@ -351,10 +366,14 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
             if (slab_exact(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2],
                            r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) {
                 const uint32_t idx = tr->idx;
-                bool take = t < r.best_t;
-                if (!take && t == r.best_t && r.best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
-                    take = shade[idx].rank > shade[r.best_idx].rank;
-                if (take) { r.best_t = t; r.best_idx = idx; }
+                if (ANYHIT) {
+                    if (candidate_occludes(r, t)) { r.best_t = t; r.best_idx = idx; r.active = false; }
+                } else {
+                    bool take = t < r.best_t;
+                    if (!take && t == r.best_t && r.best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
+                        take = shade[idx].rank > shade[r.best_idx].rank;
+                    if (take) { r.best_t = t; r.best_idx = idx; }
+                }
             }
         }
     }
@@ -362,7 +381,7 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
 
 // The spheres of one leaf against the ray of every lane: Sphere::intersect, then the same leaf rule, leaf box and
 // tie rule as a triangle (BVHNode::intersect does not look at the arm, bvh.rs:50-86).
-template <bool COUNT>
+template <bool COUNT, bool ANYHIT = false>
 __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restrict__ tris,
                                              const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
                                              LaneRay &r, unsigned long long n_active, WaveCounters &wc)
@@ -376,10 +395,14 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
             if (slab_exact(sp->bmin[0], sp->bmin[1], sp->bmin[2], sp->bmax[0], sp->bmax[1], sp->bmax[2],
                            r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) {
                 const uint32_t idx = sp->idx;
-                bool take = t < r.best_t;
-                if (!take && t == r.best_t && r.best_idx != kNone)
-                    take = shade[idx].rank > shade[r.best_idx].rank;
-                if (take) { r.best_t = t; r.best_idx = idx; }
+                if (ANYHIT) {
+                    if (candidate_occludes(r, t)) { r.best_t = t; r.best_idx = idx; r.active = false; }
+                } else {
+                    bool take = t < r.best_t;
+                    if (!take && t == r.best_t && r.best_idx != kNone)
+                        take = shade[idx].rank > shade[r.best_idx].rank;
+                    if (take) { r.best_t = t; r.best_idx = idx; }
+                }
             }
         }
     }
@@ -392,7 +415,7 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
 // exact slab test for this traversal (the multiply-based culling needs finite 1/d).
 // SPHERES = false compiles the Sphere arm out: scenes without spheres (every BASELINE configuration) run the
 // triangle-only kernel, whose register allocation the extra arm would otherwise push into scratch.
-template <bool COUNT, bool FAST, bool SPHERES = false>
+template <bool COUNT, bool FAST, bool SPHERES = false, bool ANYHIT = false>
 __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
@@ -409,13 +432,31 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
         const bool any = __ballot(r.active && box_pass(use_fast, cur, r)) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
         if (leaf && any) {
-            if (SPHERES && (cur.info & kSphereFlag)) leaf_spheres<COUNT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
-            else leaf_triangles<COUNT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
+            if (SPHERES && (cur.info & kSphereFlag))
+                leaf_spheres<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
+            else
+                leaf_triangles<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
+            if (ANYHIT) {   // lanes that found an occluder have left the walk (r.active); so does a wavefront without lanes
+                const unsigned long long still = __ballot(r.active);
+                if (still == 0ull) break;
+                if (COUNT) n_active = __popcll(still);
+            }
         }
         // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
         i = (any || leaf) ? i + 1u : cur.link;
     }
     return true;
+}
+
+// any_hit: the walk of a shadow ray.  r.limit = distance to the light point; on return r.best_idx != kNone iff the
+// sample is occluded (see candidate_occludes), r.active is consumed.
+template <bool COUNT, bool FAST, bool SPHERES = false>
+__device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                        const TriRec RTX_CONSTANT *__restrict__ tris,
+                                        const ShadeRec *__restrict__ shade, uint32_t n_nodes,
+                                        LaneRay &r, WaveCounters &wc)
+{
+    return closest_hit<COUNT, FAST, SPHERES, true>(nodes, tris, shade, n_nodes, r, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------
