@@ -211,16 +211,17 @@ int grow_buffer(T **ptr, size_t *cap, size_t bytes)
 int ensure_stream_ws(DeviceState &st, const rtx::DeviceScene &S, const rtx::TileSpec &ts, const rtx::StreamWorkspace **out)
 {
     *out = nullptr;
-    if (!(kernel_variant() & rtx::kVariantStream)) return RTX_OK;
-    const rtx::StreamWorkspaceBytes need = rtx::stream_workspace_bytes(S, ts);
+    if (!(kernel_variant() & (rtx::kVariantStream | rtx::kVariantProbe))) return RTX_OK;
+    const rtx::StreamWorkspaceBytes need = rtx::stream_workspace_bytes(S, ts, kernel_variant());
     int rc;
     if ((rc = grow_buffer(&st.ws.hits, &st.ws_cap.hits, need.hits)) != RTX_OK) return rc;
     if ((rc = grow_buffer(&st.ws.pix_slot, &st.ws_cap.pix_slot, need.pix_slot)) != RTX_OK) return rc;
     if ((rc = grow_buffer(&st.ws.tiles, &st.ws_cap.tiles, need.tiles)) != RTX_OK) return rc;
-    if ((rc = grow_buffer(&st.ws.chunks, &st.ws_cap.chunks, need.chunks)) != RTX_OK) return rc;
-    if ((rc = grow_buffer(&st.ws.results, &st.ws_cap.results, need.results)) != RTX_OK) return rc;
+    if (need.chunks && (rc = grow_buffer(&st.ws.chunks, &st.ws_cap.chunks, need.chunks)) != RTX_OK) return rc;
+    if (need.results && (rc = grow_buffer(&st.ws.results, &st.ws_cap.results, need.results)) != RTX_OK) return rc;
     if (need.acc && (rc = grow_buffer(&st.ws.acc, &st.ws_cap.acc, need.acc)) != RTX_OK) return rc;
     if ((rc = grow_buffer(&st.ws.ctr, &st.ws_cap.ctr, need.ctr)) != RTX_OK) return rc;
+    if (need.buckets && (rc = grow_buffer(&st.ws.buckets, &st.ws_cap.buckets, need.buckets)) != RTX_OK) return rc;
     *out = &st.ws;
     return RTX_OK;
 }
@@ -324,7 +325,7 @@ void rtx_scene_destroy(RtxScene *scene)
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
         void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters, st.d_redo,
-                        st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr};
+                        st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr, st.ws.buckets};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);
         if (st.ev0) (void)hipEventDestroy(st.ev0);

@@ -41,7 +41,7 @@ struct TileSpec {
 // intermediate products that the fused kernel keeps in LDS live in HBM here.  Sized for the pixels of one
 // launch (tiles x 64), grow-only, owned by the library per device.
 struct TileDesc {
-    uint32_t first;      // first hit record / result row block of the tile
+    uint32_t first;      // streamed pipeline: first hit record / result row block of the tile; probe pipeline: cost class
     uint32_t n_hit;
     uint32_t flags;      // bit 0: number the tile's rays sample-major; bit 1: queued for the reference re-render
     uint32_t pad;
@@ -58,9 +58,11 @@ struct StreamWorkspace {
     float    *results;   // hits x nb_light: |n.l| or the "occluded" marker, per tile [sample][hit pixel]
     float    *acc;       // tiles x 64 x 3 running sums, only when nb_ray > 1
     uint32_t *ctr;       // hit count, chunk count, chunk cursor
+    uint32_t *buckets;   // probe pipeline: [0] = number of scheduled tiles, [kCostBuckets + i] = i-th tile, costliest first
 };
-struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr; };
-StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts);
+struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets; };
+StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);
+constexpr uint32_t kCostBuckets = 64u;
 
 // counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits
 constexpr int kNumCounters = 8;
@@ -73,10 +75,13 @@ constexpr uint32_t kMaxLightBatch = 128u;
 // bits 1-2 = wavefronts per workgroup of the fused kernel: 0 -> 4, 1 -> 8, 2 -> 2, 3 -> 1;
 // bit 3 = streamed pipeline (three kernels, results through HBM) instead of the fused kernel.
 // bit 4 (with bit 3) = two rays per lane in the shadow kernel, packed f32 arithmetic.
+// bit 5 = probe pipeline: probe_kernel (primary hits of every tile + one probing shadow traversal that estimates the
+// tile's cost) then shade_tiles_kernel (persistent workgroups, costliest tiles first, shadow + accumulation phases).
 constexpr uint32_t kVariantStream = 8u;
 constexpr uint32_t kVariantPacked = 16u;
-constexpr uint32_t kVariantMask = 31u;
-constexpr uint32_t kDefaultVariant = 3u;
+constexpr uint32_t kVariantProbe = 32u;
+constexpr uint32_t kVariantMask = 63u;
+constexpr uint32_t kDefaultVariant = kVariantProbe | 1u;
 
 // d_wave_prof: NULL or kWaveProfWords uint64 per 8x8 tile {node_visits, tri_visits, ~t_start, t_end, primary
 // phase, slowest wave's shadow phase, accumulation phase, -} in ticks of the 100 MHz wall clock;

@@ -675,7 +675,345 @@ __global__ void __launch_bounds__(64) accumulate_kernel(DeviceScene S, TileSpec 
     }
 }
 
+// =====================================================================================================
+// Probe pipeline: the fused kernel with its first phase moved out, so that tiles can be scheduled by cost.
+// A frame's tiles differ in cost by three orders of magnitude (sky: nothing; ground: ~13 records per shadow
+// walk; mesh silhouettes and the shadow: hundreds), and a persistent workgroup that pulls a costly tile late
+// holds the frame's tail alone (profiles/r01: the last 1 % of the tiles end 10 % after the rest).
+//
+//   probe_kernel        one wavefront per tile: primary rays, closest hits, compacted hit records to HBM
+//                       (64 x 48 B per tile, read back once) — and ONE shadow walk, the tile's hit pixels towards
+//                       light sample 0, whose record count times the tile's number of 64-ray chunks is the cost
+//                       estimate.  The tile id is appended to the list of its cost class (half octaves).
+//   shade_tiles_kernel  persistent workgroups pull tiles costliest class first; phases 2 and 3 of the fused kernel.
+//
+// Same arithmetic, same order of additions, same bytes as trace_shade_kernel.
+__device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
+{
+    if (cost == 0ull) return 0u;
+    if (cost > 0x7FFFFFFFull) cost = 0x7FFFFFFFull;
+    const uint32_t c = (uint32_t)cost;
+    const uint32_t lz = 31u - (uint32_t)__clz((int)c);                 // floor(log2)
+    const uint32_t half = lz ? (c >> (lz - 1u)) & 1u : 0u;
+    const uint32_t k = 2u * lz + half + 1u;
+    return k < kCostBuckets ? k : kCostBuckets - 1u;
+}
+
+template <bool COUNT, bool FAST, bool SPHERES>
+__global__ void __launch_bounds__(64) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
+                                                   uint32_t r, StreamWorkspace W, uint8_t *__restrict__ out,
+                                                   uint32_t *__restrict__ queue, unsigned long long *__restrict__ counters)
+{
+    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile_id = blockIdx.x;
+    uint32_t px, py, ly;
+    const bool in_frame = tile_pixel(S, ts, tile_id % tiles_x, tile_id / tiles_x, lane, px, py, ly);
+    WaveCounters wc;
+    float dx, dy, dz;
+    primary_ray(S, in_frame, px, py, r, dx, dy, dz);
+    LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
+    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
+    const bool hit = ok && in_frame && pr.best_idx != kNone;
+    const unsigned long long hit_mask = __ballot(hit);
+    const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
+    const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));
+    const uint32_t first_idx = __builtin_amdgcn_readfirstlane(hit_mask ? __shfl(pr.best_idx, __ffsll((long long)hit_mask) - 1) : 0u);
+    const bool one_surface = __ballot(hit && pr.best_idx != first_idx) == 0ull;
+    // a tile queued for the reference re-render by an earlier primary ray stays queued (and is not queued twice)
+    uint32_t was_redo = 0u, counted = 0u;
+    if (r != 0u) {
+        const TileDesc old = W.tiles[tile_id];
+        was_redo = old.flags & 2u;
+        counted = old.pad;
+    }
+    uint32_t flags = (kOneSurfaceSampleMajor && one_surface) ? 1u : 0u;
+    if (!ok || was_redo) flags |= 2u;
+    if (!ok && !was_redo && lane == 0) {
+        queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_id;
+        if (COUNT && counters) {
+            atomicAdd(&counters[5], 1ull);
+            if (counted) atomicAdd(&counters[0], 0ull - (unsigned long long)counted);   // the re-render counts the tile's hits itself
+        }
+    }
+    float hx = 0.0f, hy = 0.0f, hz = 0.0f;
+    if (hit) {
+        const ShadeRec sh = S.shade[pr.best_idx];
+        HitRec h;
+        h.p[0] = hx = S.eye[0] + pr.best_t * dx;                                     // p_hit, bvh.rs:69
+        h.p[1] = hy = S.eye[1] + pr.best_t * dy;
+        h.p[2] = hz = S.eye[2] + pr.best_t * dz;
+        hit_normal<SPHERES>(sh, h.p[0], h.p[1], h.p[2], h.n[0], h.n[1], h.n[2]);     // main.rs:206
+        h.rgb[0] = sh.rgb[0]; h.rgb[1] = sh.rgb[1]; h.rgb[2] = sh.rgb[2];            // main.rs:191
+        h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
+        W.hits[(size_t)tile_id * 64u + slot] = h;
+    }
+    W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;
+    // cost probe: the walk of light sample 0 for the tile's hit pixels (its result is not used, only its length)
+    unsigned long long cost = 0;
+    if (n_hit != 0u && S.nb_light != 0u && !(flags & 2u)) {
+        const float *lp = S.light_points + 3u * (r * S.nb_light);
+        const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;
+        const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);
+        LaneRay sr = make_ray(hit, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);
+        sr.limit = dist_light;
+        WaveCounters probe;
+        (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe);
+        const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
+        cost = (probe.node_visits + probe.tri_visits + 1ull) * n_chunks;
+    }
+    // A tile without a hit is finished here (main.rs:235: the sums stay as they are), a queued tile belongs to the
+    // reference re-render: neither is scheduled for shade_tiles_kernel (cost class kNone).
+    const bool sky = n_hit == 0u && !(flags & 2u);
+    if (sky) {
+        const size_t pix = (size_t)tile_id * 64u + lane;
+        if (r + 1u == S.nb_ray) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                                   // main.rs:182
+            if (r != 0u) { a0 = W.acc[3u * pix]; a1 = W.acc[3u * pix + 1u]; a2 = W.acc[3u * pix + 2u]; }
+            if (in_frame) store_pixel(S, out, px, ly, a0, a1, a2);
+        } else if (r == 0u) {
+            W.acc[3u * pix] = 0.0f; W.acc[3u * pix + 1u] = 0.0f; W.acc[3u * pix + 2u] = 0.0f;
+        }
+    }
+    if (lane == 0) {
+        const bool count_it = !(flags & 2u);
+        const uint32_t key = (sky || (flags & 2u)) ? kNone : cost_class(cost);
+        W.tiles[tile_id] = TileDesc{key, n_hit, flags, counted + (count_it ? n_hit : 0u)};
+        if (COUNT) flush_counters<COUNT>(counters, count_it ? (unsigned long long)n_hit : 0ull, wc);
+    }
+}
+
+// Counting sort of the scheduled tiles by cost class, costliest first: W.buckets[0] = number of tiles in the order,
+// W.buckets[kCostBuckets + i] = i-th tile.  One workgroup; equal classes within a wavefront are counted by one
+// lane (neighbouring tiles mostly share a class), so the LDS atomics stay few.
+__global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, StreamWorkspace W)
+{
+    __shared__ uint32_t count[kCostBuckets], base[kCostBuckets];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < kCostBuckets) count[tid] = 0u;
+    __syncthreads();
+    constexpr uint32_t kUnroll = 8u;   // keys fetched per thread before any is consumed: the loads overlap
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u * kUnroll) {
+            uint32_t keys[kUnroll];
+#pragma unroll
+            for (uint32_t j = 0; j < kUnroll; ++j) {
+                const uint32_t i = i0 + j * 1024u + tid;
+                keys[j] = i < n_tiles ? W.tiles[i].first : kNone;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kUnroll; ++j) {
+                const uint32_t i = i0 + j * 1024u + tid;
+                const uint32_t key = keys[j];
+                unsigned long long todo = __ballot(key != kNone);
+                while (todo != 0ull) {
+                    const uint32_t k0 = __builtin_amdgcn_readfirstlane(__shfl(key, __ffsll((long long)todo) - 1));
+                    const unsigned long long same = __ballot(key == k0);
+                    uint32_t off = 0u;
+                    if (lane == (uint32_t)(__ffsll((long long)same) - 1)) off = atomicAdd(&count[k0], (uint32_t)__popcll(same));
+                    off = __shfl(off, __ffsll((long long)same) - 1);
+                    if (pass == 1 && key == k0)
+                        W.buckets[kCostBuckets + base[k0] + off + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+                    todo &= ~same;
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (tid == 0) {
+                uint32_t running = 0u;
+                for (uint32_t k = kCostBuckets; k-- != 0u;) { base[k] = running; running += count[k]; }
+                W.buckets[0] = running;
+            }
+            __syncthreads();
+            if (tid < kCostBuckets) count[tid] = 0u;
+            __syncthreads();
+        }
+    }
+}
+
+// Without the primary phase the kernel fits 64 VGPRs (8 wavefronts per SIMD, 4 workgroups per CU) with three
+// loop-invariant dwords in scratch, reloaded once per tile; measured 2.22 ms against 2.28 ms at 6 per SIMD (C3).
+#ifndef RTX_SHADE_WAVES_PER_SIMD
+#define RTX_SHADE_WAVES_PER_SIMD 8
+#endif
+
+template <bool COUNT, bool FAST, int NW, bool SPHERES>
+__global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_SHADE_WAVES_PER_SIMD)
+shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x, uint32_t n_tiles, uint32_t r,
+                   StreamWorkspace W, uint8_t *__restrict__ out, uint32_t *__restrict__ queue,
+                   unsigned long long *__restrict__ counters)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *const l_light = lds;
+    float *const l_hit = l_light + 3u * batch;
+    float *const l_res = l_hit + 64u * kHitStride;
+    const uint32_t res_stride = lds_res_stride(batch);
+    float *const l_pix = l_res + 64u * res_stride;                                    // per pixel: running sums r,g,b + hit slot
+    uint32_t *const l_ctl = reinterpret_cast<uint32_t *>(l_pix + 64u * 4u);           // [1] redo flag, [3] tile
+
+    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveCounters wc;
+    const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
+    static_assert(sizeof(HitRec) == kHitStride * sizeof(float), "the LDS hit record is the HBM hit record");
+
+    for (;;) {
+        if (threadIdx.x == 0) {
+            // q-th tile, costliest class first
+            const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
+            l_ctl[3] = q < W.buckets[0] ? W.buckets[kCostBuckets + q] : kNone;
+            l_ctl[1] = 0u;
+        }
+        __syncthreads();
+        const uint32_t tile_id = __builtin_amdgcn_readfirstlane(l_ctl[3]);
+        if (tile_id == kNone) break;
+        const uint32_t tile_x = tile_id % tiles_x, tile_y = tile_id / tiles_x;
+        const TileDesc td = W.tiles[tile_id];
+        const uint32_t n_hit = __builtin_amdgcn_readfirstlane(td.n_hit);
+        const uint32_t tflags = __builtin_amdgcn_readfirstlane(td.flags);
+        const bool sample_major = (tflags & 1u) != 0u;
+        const bool skip = (tflags & 2u) != 0u;      // already queued for the reference re-render
+        if (!skip) {
+            const float *src = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u);
+            for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = src[k];
+            if (wave == 0) {
+                const size_t pix = (size_t)tile_id * 64u + lane;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                               // main.rs:182
+                if (r != 0u) { a0 = W.acc[3u * pix]; a1 = W.acc[3u * pix + 1u]; a2 = W.acc[3u * pix + 2u]; }
+                l_pix[4u * lane] = a0; l_pix[4u * lane + 1u] = a1; l_pix[4u * lane + 2u] = a2;
+                reinterpret_cast<uint32_t *>(l_pix)[4u * lane + 3u] = W.pix_slot[pix];
+            }
+            __syncthreads();
+            if (n_hit != 0u) {                                                        // else main.rs:235
+                for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                 // main.rs:193, in batches that fit LDS
+                    const uint32_t bc = (S.nb_light - b0 < batch) ? S.nb_light - b0 : batch;
+                    for (uint32_t k = threadIdx.x; k < 3u * bc; k += 64u * NW)
+                        l_light[k] = S.light_points[3u * (r * S.nb_light + b0) + k]; // main.rs:194-196 (hoisted to the host)
+                    __syncthreads();
+                    // phase 2: shadow rays, one work-item per (hit pixel, sample)
+                    const uint32_t total = n_hit * bc;
+                    const uint32_t div = sample_major ? n_hit : bc;
+                    for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
+                        ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
+                        const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
+                        if (!ok && lane == 0) l_ctl[1] = 1u;
+                        shadow_result(l_hit, l_res, res_stride, sr);
+                    }
+                    __syncthreads();
+                    // phase 3: ordered accumulation, one work-item per pixel (wave 0)
+                    if (wave == 0) {
+                        const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
+                        const bool hit = slot != kNone;
+                        float acc_r = l_pix[4u * lane], acc_g = l_pix[4u * lane + 1u], acc_b = l_pix[4u * lane + 2u];
+                        const float *h = l_hit + kHitStride * (hit ? slot : 0u);
+                        const float cr = h[6], cg = h[7], cb = h[8];
+                        // grey surfaces (every BASELINE scene): the three channel sums are the same f32 sequence
+                        const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && acc_r == acc_g && acc_g == acc_b)) == 0ull;
+                        if (hit) {
+                            const float *res = l_res + slot * res_stride;
+                            if (grey_tile) {
+                                uint32_t i = 0;
+                                for (; i + 4u <= bc; i += 4u) {                       // i ascending, main.rs:209-216
+                                    const float l0 = res[i], l1 = res[i + 1u], l2 = res[i + 2u], l3 = res[i + 3u];
+                                    const float q0 = (cr * l0) / denom, q1 = (cr * l1) / denom, q2 = (cr * l2) / denom,
+                                                q3 = (cr * l3) / denom;
+                                    if (!(l0 < 0.0f)) acc_r = acc_r + q0;
+                                    if (!(l1 < 0.0f)) acc_r = acc_r + q1;
+                                    if (!(l2 < 0.0f)) acc_r = acc_r + q2;
+                                    if (!(l3 < 0.0f)) acc_r = acc_r + q3;
+                                }
+                                for (; i < bc; ++i) {
+                                    const float lnd = res[i];
+                                    if (!(lnd < 0.0f)) acc_r = acc_r + ((cr * lnd) / denom);
+                                }
+                                acc_g = acc_r;
+                                acc_b = acc_r;
+                            } else {
+                                for (uint32_t i = 0; i < bc; ++i) {                   // i ascending, main.rs:209-216
+                                    const float lnd = res[i];
+                                    if (!(lnd < 0.0f)) {
+                                        acc_r = acc_r + ((cr * lnd) / denom);
+                                        acc_g = acc_g + ((cg * lnd) / denom);
+                                        acc_b = acc_b + ((cb * lnd) / denom);
+                                    }
+                                }
+                            }
+                            l_pix[4u * lane] = acc_r; l_pix[4u * lane + 1u] = acc_g; l_pix[4u * lane + 2u] = acc_b;
+                        }
+                    }
+                    __syncthreads();   // results and light points are overwritten by the next batch
+                }
+            }
+            if (wave == 0) {
+                if (l_ctl[1] != 0u) {   // a hard shadow direction: reference_tiles_kernel redoes the tile and counts its hits
+                    if (lane == 0) {
+                        queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_id;
+                        W.tiles[tile_id].flags = tflags | 2u;
+                        if (COUNT && counters) {
+                            atomicAdd(&counters[5], 1ull);
+                            atomicAdd(&counters[0], 0ull - (unsigned long long)td.pad);
+                        }
+                    }
+                } else if (r + 1u < S.nb_ray) {
+                    const size_t pix = (size_t)tile_id * 64u + lane;
+                    W.acc[3u * pix] = l_pix[4u * lane]; W.acc[3u * pix + 1u] = l_pix[4u * lane + 1u];
+                    W.acc[3u * pix + 2u] = l_pix[4u * lane + 2u];
+                } else {
+                    uint32_t px, py, ly;
+                    if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly))
+                        store_pixel(S, out, px, ly, l_pix[4u * lane], l_pix[4u * lane + 1u], l_pix[4u * lane + 2u]);
+                }
+            }
+        }
+        __syncthreads();   // the control words and hit records are rewritten by the next tile
+    }
+    if (COUNT && lane == 0) flush_counters<COUNT>(counters, 0ull, wc);
+}
+
 namespace {
+
+template <bool COUNT, bool FAST, bool SPHERES>
+hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
+                        const StreamWorkspace &W, unsigned long long *d_counters, hipStream_t stream)
+{
+    constexpr int NW = 8;
+    const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
+    const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
+    const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    static thread_local int cached_dev = -1, cached_blocks = 0;
+    static thread_local size_t cached_lds = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != cached_dev || lds_bytes != cached_lds) {
+        int per_cu = 0, cus = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_tiles_kernel<COUNT, FAST, NW, SPHERES>, 64 * NW, lds_bytes);
+        if (e != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        cached_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+        cached_dev = dev;
+        cached_lds = lds_bytes;
+    }
+    const uint32_t grid = n_tiles < static_cast<uint32_t>(cached_blocks) ? n_tiles : static_cast<uint32_t>(cached_blocks);
+    if ((e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
+        if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>), dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, n_tiles,
+                           r, W, d_out, d_redo, d_counters);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, W);
+        hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
+                           batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((reference_tiles_kernel<COUNT, SPHERES>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream,
+                       S, ts, tiles_x, d_out, d_redo, d_counters);
+    return hipGetLastError();
+}
 
 template <bool COUNT, bool FAST, bool PACKED>
 hipError_t launch_stream(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
@@ -783,18 +1121,20 @@ size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts)
     return sizeof(uint32_t) * (kQueueHeader + static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u));
 }
 
-StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts)
+StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant)
 {
     const size_t tiles = static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u);
     const size_t pixels = tiles * 64u;
+    const bool streamed = (variant & kVariantStream) != 0u, probe = (variant & kVariantProbe) != 0u;
     StreamWorkspaceBytes b;
     b.hits = pixels * sizeof(HitRec);
     b.pix_slot = pixels * sizeof(uint32_t);
     b.tiles = tiles * sizeof(TileDesc);
-    b.chunks = (pixels * S.nb_light / 64u + tiles + 1u) * sizeof(uint2);
-    b.results = pixels * (S.nb_light ? S.nb_light : 1u) * sizeof(float);
+    b.chunks = streamed ? (pixels * S.nb_light / 64u + tiles + 1u) * sizeof(uint2) : 0u;
+    b.results = streamed ? pixels * (S.nb_light ? S.nb_light : 1u) * sizeof(float) : 0u;
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);
+    b.buckets = probe ? (kCostBuckets + tiles) * sizeof(uint32_t) : 0u;
     return b;
 }
 
@@ -803,6 +1143,21 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
                               unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream)
 {
     if (ts.local_rows == 0) return hipSuccess;
+    if ((variant & kVariantProbe) && ws && !d_wave_prof) {
+        const bool fast = (variant & 1u) != 0u;
+        if (S.n_spheres) {
+            if (d_counters)
+                return fast ? launch_probe<true, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                            : launch_probe<true, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+            return fast ? launch_probe<false, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                        : launch_probe<false, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+        }
+        if (d_counters)
+            return fast ? launch_probe<true, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                        : launch_probe<true, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+        return fast ? launch_probe<false, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream)
+                    : launch_probe<false, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+    }
     if ((variant & kVariantStream) && ws && !d_wave_prof && S.n_spheres == 0u) {   // the streamed kernels are triangle-only
         const bool fast = (variant & 1u) != 0u, packed = (variant & kVariantPacked) != 0u;
         if (d_counters) {

@@ -299,7 +299,7 @@ def test_every_kernel_variant_gives_the_same_bytes(samples_seeded):
     ) % (ROOT, model("big_bunny.obj"))
     import hashlib
     want = hashlib.sha1(np.ascontiguousarray(ref).tobytes()).hexdigest()
-    for variant in (0, 1, 2, 3, 5, 7, 8, 9, 25):
+    for variant in (0, 1, 2, 3, 5, 7, 8, 9, 25, 34, 35):
         env = dict(os.environ, RTX_VARIANT=str(variant))
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
