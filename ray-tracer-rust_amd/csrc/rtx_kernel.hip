@@ -149,6 +149,19 @@ __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, f
     if (s.valid) l_res[s.hp * res_stride + s.si] = lit ? lnd : kOccluded;
 }
 
+// The same for a tile whose hit pixels are all grey (red == green == blue >= 0, equal running sums): the lane stores
+// the sample's contribution (color.red * lnd) / denom itself (main.rs:211-215), so that the ordered accumulation,
+// which one wavefront does alone, is left with the additions.  Contributions are >= 0 (or NaN), the marker is not.
+__device__ __forceinline__ void shadow_result_grey(const float *__restrict__ l_hit, float *__restrict__ l_res,
+                                                   uint32_t res_stride, const ShadowRay &s, float denom)
+{
+    const float *h = l_hit + kHitStride * s.hp;
+    const LaneRay &r = s.ray;
+    const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
+    const bool lit = r.best_idx == kNone;
+    if (s.valid) l_res[s.hp * res_stride + s.si] = lit ? (h[6] * lnd) / denom : kOccluded;
+}
+
 __device__ __forceinline__ void store_pixel(const DeviceScene &S, uint8_t *__restrict__ out, uint32_t px, uint32_t ly,
                                             float r, float g, float b)
 {
@@ -888,6 +901,15 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 reinterpret_cast<uint32_t *>(l_pix)[4u * lane + 3u] = W.pix_slot[pix];
             }
             __syncthreads();
+            if (wave == 0) {   // grey tile (every BASELINE scene): the three channel sums are the same f32 sequence
+                const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
+                const bool hit = slot != kNone;
+                const float *h = l_hit + kHitStride * (hit ? slot : 0u);
+                const float cr = h[6], cg = h[7], cb = h[8];
+                const float a0 = l_pix[4u * lane], a1 = l_pix[4u * lane + 1u], a2 = l_pix[4u * lane + 2u];
+                const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && cr >= 0.0f && a0 == a1 && a1 == a2)) == 0ull;
+                if (lane == 0) l_ctl[2] = grey_tile ? 1u : 0u;   // read behind the barrier that publishes the light points
+            }
             if (n_hit != 0u) {                                                        // else main.rs:235
                 for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                 // main.rs:193, in batches that fit LDS
                     const uint32_t bc = (S.nb_light - b0 < batch) ? S.nb_light - b0 : batch;
@@ -897,11 +919,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // phase 2: shadow rays, one work-item per (hit pixel, sample)
                     const uint32_t total = n_hit * bc;
                     const uint32_t div = sample_major ? n_hit : bc;
+                    const bool grey_tile = __builtin_amdgcn_readfirstlane(l_ctl[2]) != 0u;
                     for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                         ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
                         const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
                         if (!ok && lane == 0) l_ctl[1] = 1u;
-                        shadow_result(l_hit, l_res, res_stride, sr);
+                        if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
+                        else shadow_result(l_hit, l_res, res_stride, sr);
                     }
                     __syncthreads();
                     // phase 3: ordered accumulation, one work-item per pixel (wave 0)
@@ -911,24 +935,12 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         float acc_r = l_pix[4u * lane], acc_g = l_pix[4u * lane + 1u], acc_b = l_pix[4u * lane + 2u];
                         const float *h = l_hit + kHitStride * (hit ? slot : 0u);
                         const float cr = h[6], cg = h[7], cb = h[8];
-                        // grey surfaces (every BASELINE scene): the three channel sums are the same f32 sequence
-                        const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && acc_r == acc_g && acc_g == acc_b)) == 0ull;
                         if (hit) {
                             const float *res = l_res + slot * res_stride;
                             if (grey_tile) {
-                                uint32_t i = 0;
-                                for (; i + 4u <= bc; i += 4u) {                       // i ascending, main.rs:209-216
-                                    const float l0 = res[i], l1 = res[i + 1u], l2 = res[i + 2u], l3 = res[i + 3u];
-                                    const float q0 = (cr * l0) / denom, q1 = (cr * l1) / denom, q2 = (cr * l2) / denom,
-                                                q3 = (cr * l3) / denom;
-                                    if (!(l0 < 0.0f)) acc_r = acc_r + q0;
-                                    if (!(l1 < 0.0f)) acc_r = acc_r + q1;
-                                    if (!(l2 < 0.0f)) acc_r = acc_r + q2;
-                                    if (!(l3 < 0.0f)) acc_r = acc_r + q3;
-                                }
-                                for (; i < bc; ++i) {
-                                    const float lnd = res[i];
-                                    if (!(lnd < 0.0f)) acc_r = acc_r + ((cr * lnd) / denom);
+                                for (uint32_t i = 0; i < bc; ++i) {                   // i ascending, main.rs:209-216
+                                    const float q = res[i];                           // (color.red * lnd) / denom, or the marker
+                                    if (!(q < 0.0f)) acc_r = acc_r + q;
                                 }
                                 acc_g = acc_r;
                                 acc_b = acc_r;

@@ -297,7 +297,10 @@ __device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, flo
     LaneRay r;
     r.ox = ox; r.oy = oy; r.oz = oz;
     r.dx = dx; r.dy = dy; r.dz = dz;
-    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    // Culling only: v_rcp_f32 (1 ulp, e_r <= 2^-23 instead of 2^-24) replaces the ten-instruction IEEE division.
+    // The bound of slab_fast_fma becomes 5*2^-24 |t| + 1.01*2^-24 |o/d|, still three times inside its widening
+    // (slab_fast: 6*2^-24 against 16*2^-24).  Regular directions only reach these values: 2^-60 <= |d| <= 2.
+    r.ix = __builtin_amdgcn_rcpf(dx); r.iy = __builtin_amdgcn_rcpf(dy); r.iz = __builtin_amdgcn_rcpf(dz);
     const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
     r.nx = -px; r.ny = -py; r.nz = -pz;
     r.slack0 = __builtin_fmaf(fabsf(px) + fabsf(py) + fabsf(pz), 0x1p-21f, 0x1p-100f);
