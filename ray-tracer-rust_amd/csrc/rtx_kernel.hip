@@ -254,7 +254,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             const float t = pr.best_t;
             const uint32_t idx = pr.best_idx;
             const bool hit = in_frame && idx != kNone;
-            const unsigned long long hit_mask = __ballot(hit);
+            const unsigned long long hit_mask = ballot(hit);
             const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));       // compacted index of this pixel
             if (COUNT) primary_hits += __popcll(hit_mask);
             if (hit) {
@@ -273,7 +273,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             // Several triangles (mesh surface, silhouettes): origins sit in different BVH leaves, a pixel's own
             // samples (one origin -> the small light) are tighter, number pixel-major.
             const uint32_t first_idx = __builtin_amdgcn_readfirstlane(hit_mask ? __shfl(idx, __ffsll((long long)hit_mask) - 1) : 0u);
-            const bool one_surface = __ballot(hit && idx != first_idx) == 0ull;
+            const bool one_surface = ballot(hit && idx != first_idx) == 0ull;
             if (lane == 0) {
                 l_ctl[0] = (uint32_t)__popcll(hit_mask);
                 if (!ok) l_ctl[1] = 1u;
@@ -316,7 +316,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     const float *h = l_hit + kHitStride * (hit ? slot : 0u);
                     const float cr = h[6], cg = h[7], cb = h[8];
                     // grey surfaces (every BASELINE scene): the three channel sums are the same f32 sequence
-                    const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && acc_r == acc_g && acc_g == acc_b)) == 0ull;
+                    const bool grey_tile = ballot(hit && !(cr == cg && cg == cb && acc_r == acc_g && acc_g == acc_b)) == 0ull;
                     if (hit) {
                         const float *res = l_res + slot * res_stride;
                         if (grey_tile) {
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
             closest_hit_reference<COUNT, SPHERES>(stream, tris, S.shade, n_stream, have_ref, in_frame, S.eye[0], S.eye[1], S.eye[2],
                                          dx, dy, dz, t, idx, wc);
             const bool hit = in_frame && idx != kNone;
-            const unsigned long long hit_mask = __ballot(hit);
+            const unsigned long long hit_mask = ballot(hit);
             if (hit_mask == 0ull) continue;
             if (COUNT) primary_hits += __popcll(hit_mask);
             float hx = 0.0f, hy = 0.0f, hz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(64) primary_kernel(DeviceScene S, TileSpec ts,
     LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
     const bool ok = closest_hit<COUNT, FAST>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
     const bool hit = ok && in_frame && pr.best_idx != kNone;
-    const unsigned long long hit_mask = __ballot(hit);
+    const unsigned long long hit_mask = ballot(hit);
     const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
     const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));
     uint32_t first = 0, chunk_base = 0;
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(64) primary_kernel(DeviceScene S, TileSpec ts,
     first = __builtin_amdgcn_readfirstlane(first);
     chunk_base = __builtin_amdgcn_readfirstlane(chunk_base);
     const uint32_t first_idx = __builtin_amdgcn_readfirstlane(hit_mask ? __shfl(pr.best_idx, __ffsll((long long)hit_mask) - 1) : 0u);
-    const bool one_surface = __ballot(hit && pr.best_idx != first_idx) == 0ull;
+    const bool one_surface = ballot(hit && pr.best_idx != first_idx) == 0ull;
     uint32_t flags = (kOneSurfaceSampleMajor && one_surface) ? 1u : 0u;
     if (!ok) {   // a hard primary direction: the whole tile goes to the reference re-render
         flags |= 2u;
@@ -729,11 +729,11 @@ __global__ void __launch_bounds__(64) probe_kernel(DeviceScene S, TileSpec ts, u
     LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
     const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
     const bool hit = ok && in_frame && pr.best_idx != kNone;
-    const unsigned long long hit_mask = __ballot(hit);
+    const unsigned long long hit_mask = ballot(hit);
     const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
     const uint32_t slot = __popcll(hit_mask & ((1ull << lane) - 1ull));
     const uint32_t first_idx = __builtin_amdgcn_readfirstlane(hit_mask ? __shfl(pr.best_idx, __ffsll((long long)hit_mask) - 1) : 0u);
-    const bool one_surface = __ballot(hit && pr.best_idx != first_idx) == 0ull;
+    const bool one_surface = ballot(hit && pr.best_idx != first_idx) == 0ull;
     // a tile queued for the reference re-render by an earlier primary ray stays queued (and is not queued twice)
     uint32_t was_redo = 0u, counted = 0u;
     if (r != 0u) {
@@ -819,10 +819,10 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
             for (uint32_t j = 0; j < kUnroll; ++j) {
                 const uint32_t i = i0 + j * 1024u + tid;
                 const uint32_t key = keys[j];
-                unsigned long long todo = __ballot(key != kNone);
+                unsigned long long todo = ballot(key != kNone);
                 while (todo != 0ull) {
                     const uint32_t k0 = __builtin_amdgcn_readfirstlane(__shfl(key, __ffsll((long long)todo) - 1));
-                    const unsigned long long same = __ballot(key == k0);
+                    const unsigned long long same = ballot(key == k0);
                     uint32_t off = 0u;
                     if (lane == (uint32_t)(__ffsll((long long)same) - 1)) off = atomicAdd(&count[k0], (uint32_t)__popcll(same));
                     off = __shfl(off, __ffsll((long long)same) - 1);
@@ -907,7 +907,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 const float *h = l_hit + kHitStride * (hit ? slot : 0u);
                 const float cr = h[6], cg = h[7], cb = h[8];
                 const float a0 = l_pix[4u * lane], a1 = l_pix[4u * lane + 1u], a2 = l_pix[4u * lane + 2u];
-                const bool grey_tile = __ballot(hit && !(cr == cg && cg == cb && cr >= 0.0f && a0 == a1 && a1 == a2)) == 0ull;
+                const bool grey_tile = ballot(hit && !(cr == cg && cg == cb && cr >= 0.0f && a0 == a1 && a1 == a2)) == 0ull;
                 if (lane == 0) l_ctl[2] = grey_tile ? 1u : 0u;   // read behind the barrier that publishes the light points
             }
             if (n_hit != 0u) {                                                        // else main.rs:235

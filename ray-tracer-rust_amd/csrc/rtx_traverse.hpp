@@ -43,6 +43,10 @@ namespace {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr float kOccluded = -1.0f;   // |n.l| is never negative; marks an occluded sample in LDS
 
+// wave64 vote on a predicate that already lives in a lane mask: HIP's __ballot(int) first turns the bool into an
+// integer per lane and compares it again (two vector instructions per vote, one vote per node)
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 struct WaveCounters {
     unsigned long long box_tests = 0, tri_tests = 0, node_visits = 0, tri_visits = 0;
 };
@@ -112,13 +116,15 @@ __device__ __forceinline__ bool slab_fast_fma(float lox, float loy, float loz, f
 
 // a node record through the constant address space (scalar loads); field-wise because a struct copy
 // across address spaces has no implicit constructor
+// (the stream in HBM is in NodeDev order, see scene_prep.h; the pointer type only carries the record size)
 __device__ __forceinline__ NodeRec load_node(const NodeRec RTX_CONSTANT *p)
 {
+    const NodeDev RTX_CONSTANT *d = (const NodeDev RTX_CONSTANT *)p;
     NodeRec r;
-    r.bmin[0] = p->bmin[0]; r.bmin[1] = p->bmin[1]; r.bmin[2] = p->bmin[2];
-    r.link = p->link;
-    r.bmax[0] = p->bmax[0]; r.bmax[1] = p->bmax[1]; r.bmax[2] = p->bmax[2];
-    r.info = p->info;
+    r.bmin[0] = d->lox; r.bmin[1] = d->loy; r.bmin[2] = d->loz;
+    r.link = d->link;
+    r.bmax[0] = d->hix; r.bmax[1] = d->hiy; r.bmax[2] = d->hiz;
+    r.info = d->info;
     return r;
 }
 
@@ -205,7 +211,7 @@ __device__ __forceinline__ void closest_hit_reference(const NodeRec RTX_CONSTANT
     best_t = __builtin_inff();
     best_idx = kNone;
     unsigned long long n_active = 0;
-    if (COUNT) n_active = __popcll(__ballot(active));
+    if (COUNT) n_active = __popcll(ballot(active));
     uint32_t resume = 0;   // per lane: first stream position at which this lane is alive again
     uint32_t i = 0;
     while (i < n_nodes) {
@@ -216,7 +222,7 @@ __device__ __forceinline__ void closest_hit_reference(const NodeRec RTX_CONSTANT
         const bool pass = live && slab_exact(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1],
                                              cur.bmax[2], ox, oy, oz, dx, dy, dz);               // bvh.rs:52
         if (live && !pass) resume = after;
-        const bool any = __ballot(pass) != 0ull;
+        const bool any = ballot(pass) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
         if (leaf && any) {
             const uint32_t first = cur.info & kLeafIndexMask;
@@ -316,10 +322,47 @@ __device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, flo
 #define RTX_CULL_FMA 1
 #endif
 
+// slab_fast_fma with the six plane distances as three packed fused multiply-adds (v_pk_fma_f32: two IEEE f32 fmas per
+// instruction, each half rounded like the scalar one).  The pairs are the adjacent registers of the node record.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool slab_fast_fma_packed(const NodeRec &n, const LaneRay &r)
+{
+    const pk2 ixy = {r.ix, r.iy}, nxy = {r.nx, r.ny}, izz = {r.iz, r.iz}, nzz = {r.nz, r.nz};
+    const pk2 a = __builtin_elementwise_fma(pk2{n.bmin[0], n.bmin[1]}, ixy, nxy);   // near/far of x, y: low planes
+    const pk2 b = __builtin_elementwise_fma(pk2{n.bmax[0], n.bmax[1]}, ixy, nxy);   //                   high planes
+    const pk2 c = __builtin_elementwise_fma(pk2{n.bmin[2], n.bmax[2]}, izz, nzz);   // z: low, high
+    const float t_in = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(c.x, c.y));
+    const float t_out = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(c.x, c.y));
+    const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, r.slack0);
+    return !(t_in - t_out > slack) && !(t_out < r.behind);   // written so that a NaN can only accept
+}
+
+// The same test as the wave's vote: the lanes whose ray may pass the box.  Each comparison is voted on its own —
+// a vote on a compare IS the compare's lane mask, while a vote on the AND of two compares costs two more vector
+// instructions (the compiler rebuilds a per-lane integer and compares it again) — and the masks are combined by
+// the scalar unit.
+__device__ __forceinline__ unsigned long long slab_fast_fma_packed_mask(const NodeRec &n, const LaneRay &r)
+{
+    const pk2 ixy = {r.ix, r.iy}, nxy = {r.nx, r.ny}, izz = {r.iz, r.iz}, nzz = {r.nz, r.nz};
+    const pk2 a = __builtin_elementwise_fma(pk2{n.bmin[0], n.bmin[1]}, ixy, nxy);
+    const pk2 b = __builtin_elementwise_fma(pk2{n.bmax[0], n.bmax[1]}, ixy, nxy);
+    const pk2 c = __builtin_elementwise_fma(pk2{n.bmin[2], n.bmax[2]}, izz, nzz);
+    const float t_in = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(c.x, c.y));
+    const float t_out = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(c.x, c.y));
+    const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, r.slack0);
+    return ballot(!(t_in - t_out > slack)) & ballot(!(t_out < r.behind));   // a NaN can only accept
+}
+
+#ifndef RTX_CULL_PACKED
+#define RTX_CULL_PACKED 1
+#endif
+
 __device__ __forceinline__ bool box_pass(bool use_fast, const NodeRec &n, const LaneRay &r)
 {
     if (use_fast) {
-#if RTX_CULL_FMA
+#if RTX_CULL_FMA && RTX_CULL_PACKED
+        return slab_fast_fma_packed(n, r);
+#elif RTX_CULL_FMA
         return slab_fast_fma(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ix, r.iy, r.iz,
                              r.nx, r.ny, r.nz, r.slack0, r.behind);
 #else
@@ -327,6 +370,15 @@ __device__ __forceinline__ bool box_pass(bool use_fast, const NodeRec &n, const 
 #endif
     }
     return slab_exact(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+}
+
+// lanes (of any kind, with or without a ray) whose box test passes
+__device__ __forceinline__ unsigned long long box_mask(bool use_fast, const NodeRec &n, const LaneRay &r)
+{
+#if RTX_CULL_FMA && RTX_CULL_PACKED
+    if (use_fast) return slab_fast_fma_packed_mask(n, r);
+#endif
+    return ballot(box_pass(use_fast, n, r));
 }
 
 #ifndef RTX_TRIANGLE_EARLY_OUT
@@ -357,7 +409,7 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
         const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;                   // :79
         const bool out_u = u < 0.0f || u > 1.0f;                                     // :80
         // no lane can hit this triangle any more: skip the second half of the test for the whole wavefront
-        if (kTriangleEarlyOut && __ballot(r.active && !parallel && !out_u) == 0ull) continue;
+        if (kTriangleEarlyOut && ballot(r.active && !parallel && !out_u) == 0ull) continue;
         const float qvx = tvy * e1z - tvz * e1y;                                     // :84
         const float qvy = tvz * e1x - tvx * e1z;
         const float qvz = tvx * e1y - tvy * e1x;
@@ -424,15 +476,16 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                             LaneRay &r, WaveCounters &wc)
 {
-    if (__ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
-    const bool use_fast = FAST && __ballot(r.active && !direction_is_regular(r.dx, r.dy, r.dz)) == 0ull;
+    if (ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
+    const bool use_fast = FAST && ballot(r.active && !direction_is_regular(r.dx, r.dy, r.dz)) == 0ull;
+    unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
     unsigned long long n_active = 0;
-    if (COUNT) n_active = __popcll(__ballot(r.active));
+    if (COUNT) n_active = __popcll(alive);
     uint32_t i = 0;
     while (i < n_nodes) {
         const NodeRec cur = load_node(nodes + i);
         const bool leaf = (cur.info & kLeafFlag) != 0u;
-        const bool any = __ballot(r.active && box_pass(use_fast, cur, r)) != 0ull;
+        const bool any = (box_mask(use_fast, cur, r) & alive) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
         if (leaf && any) {
             if (SPHERES && (cur.info & kSphereFlag))
@@ -440,9 +493,9 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
             else
                 leaf_triangles<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
             if (ANYHIT) {   // lanes that found an occluder have left the walk (r.active); so does a wavefront without lanes
-                const unsigned long long still = __ballot(r.active);
-                if (still == 0ull) break;
-                if (COUNT) n_active = __popcll(still);
+                alive = ballot(r.active);
+                if (alive == 0ull) break;
+                if (COUNT) n_active = __popcll(alive);
             }
         }
         // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
@@ -574,12 +627,12 @@ __device__ __forceinline__ bool closest_hit2(const NodeRec RTX_CONSTANT *__restr
 {
     const bool hard = (r.active0 && direction_is_hard(r.dx.x, r.dy.x, r.dz.x)) ||
                       (r.active1 && direction_is_hard(r.dx.y, r.dy.y, r.dz.y));
-    if (__ballot(hard) != 0ull) return false;
+    if (ballot(hard) != 0ull) return false;
     const bool irregular = (r.active0 && !direction_is_regular(r.dx.x, r.dy.x, r.dz.x)) ||
                            (r.active1 && !direction_is_regular(r.dx.y, r.dy.y, r.dz.y));
-    const bool use_fast = FAST && __ballot(irregular) == 0ull;
+    const bool use_fast = FAST && ballot(irregular) == 0ull;
     unsigned long long n_active = 0;
-    if (COUNT) n_active = __popcll(__ballot(r.active0)) + __popcll(__ballot(r.active1));
+    if (COUNT) n_active = __popcll(ballot(r.active0)) + __popcll(ballot(r.active1));
     uint32_t i = 0;
     while (i < n_nodes) {
         const NodeRec cur = load_node(nodes + i);
@@ -593,7 +646,7 @@ __device__ __forceinline__ bool closest_hit2(const NodeRec RTX_CONSTANT *__restr
             p1 = slab_exact(cur.bmin[0], cur.bmin[1], cur.bmin[2], cur.bmax[0], cur.bmax[1], cur.bmax[2],
                             r.ox.y, r.oy.y, r.oz.y, r.dx.y, r.dy.y, r.dz.y);
         }
-        const bool any = __ballot((r.active0 && p0) || (r.active1 && p1)) != 0ull;
+        const bool any = ballot((r.active0 && p0) || (r.active1 && p1)) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
         if (leaf && any) leaf_triangles2<COUNT>(tris, shade, cur.info & ~kLeafFlag, cur.link, r, n_active, wc);
         i = (any || leaf) ? i + 1u : cur.link;

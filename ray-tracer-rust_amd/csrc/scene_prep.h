@@ -29,6 +29,21 @@ struct NodeRec {
     uint32_t info;
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+// The same eight dwords in the order the kernel fetches them.  The multiply-based box test is three packed
+// fused multiply-adds (v_pk_fma_f32: two planes per instruction), whose scalar operands must be adjacent
+// registers of the 32-byte scalar load: (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z).
+struct NodeDev {
+    float    lox, loy, hix, hiy, loz, hiz;
+    uint32_t link, info;
+};
+static_assert(sizeof(NodeDev) == sizeof(NodeRec), "NodeDev is a permutation of NodeRec");
+inline std::vector<NodeDev> nodes_in_device_order(const std::vector<NodeRec> &v)
+{
+    std::vector<NodeDev> out(v.size());
+    for (size_t i = 0; i < v.size(); ++i)
+        out[i] = NodeDev{v[i].bmin[0], v[i].bmin[1], v[i].bmax[0], v[i].bmax[1], v[i].bmin[2], v[i].bmax[2], v[i].link, v[i].info};
+    return out;
+}
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kSphereFlag = 0x40000000u;
 constexpr uint32_t kLeafIndexMask = 0x3FFFFFFFu;
