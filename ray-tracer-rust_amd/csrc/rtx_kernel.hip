@@ -132,7 +132,9 @@ __device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit,
     const float hx = h[0], hy = h[1], hz = h[2];
     const float vx = l_light[3u * s.si] - hx, vy = l_light[3u * s.si + 1u] - hy, vz = l_light[3u * s.si + 2u] - hz;   // p - orig
     const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                     // main.rs:202
-    s.ray = make_ray(valid, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);   // main.rs:201
+    float sx, sy, sz;
+    divide3_ieee(vx, vy, vz, dist_light, sx, sy, sz);                                 // Ray::new, main.rs:201 -> ray.rs:15
+    s.ray = make_ray(valid, hx, hy, hz, sx, sy, sz);
     s.ray.limit = dist_light;
     s.valid = valid;
     return s;

@@ -401,6 +401,29 @@ __device__ __forceinline__ float reciprocal_ieee(float x)
     return __builtin_fmaf(y0, e, y0);
 }
 
+// (ax, ay, az) / b with one reciprocal: y = reciprocal_ieee(b), then per quotient the steps of the compiler's own IEEE
+// division — q0 = a*y, r0 = a - b*q0, q1 = q0 + r0*y, r1 = a - b*q1, q = q1 + r1*y, all residuals fused — without
+// its range scaling (v_div_scale) and special-case fix-up (v_div_fixup), which do nothing while
+// 2^-60 <= |a| and b <= 2^60 (they act below 2^-103 / on exponent differences beyond 96, and on zeros, infinities,
+// NaNs).  Same instructions on the same values: the same bits (tools/div_shared_check.hip: 1.4e11 pairs, 0
+// differences).  A wavefront holding any lane outside the range — a zero component, for one — divides the slow way.
+// Precondition (callers divide a vector by its own length): |a| <= 2 b, so the exponents never differ by 96.
+__device__ __forceinline__ void divide3_ieee(float ax, float ay, float az, float b, float &qx, float &qy, float &qz)
+{
+    const float smallest = fminf(fminf(fabsf(ax), fabsf(ay)), fabsf(az));
+    if ((ballot(smallest >= 0x1p-60f) & ballot(fabsf(b) <= 0x1p60f) & ballot(fabsf(b) >= 0x1p-60f)) !=
+        ballot(true)) {
+        qx = ax / b; qy = ay / b; qz = az / b;
+        return;
+    }
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float y = __builtin_fmaf(y0, __builtin_fmaf(-b, y0, 1.0f), y0);
+    float q0, r0, q1, r1;
+    q0 = ax * y; r0 = __builtin_fmaf(-b, q0, ax); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, ax); qx = __builtin_fmaf(r1, y, q1);
+    q0 = ay * y; r0 = __builtin_fmaf(-b, q0, ay); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, ay); qy = __builtin_fmaf(r1, y, q1);
+    q0 = az * y; r0 = __builtin_fmaf(-b, q0, az); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, az); qz = __builtin_fmaf(r1, y, q1);
+}
+
 template <bool COUNT, bool ANYHIT = false>
 __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
                                                const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
@@ -493,9 +516,15 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                             LaneRay &r, WaveCounters &wc)
 {
-    if (ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
-    const bool use_fast = FAST && ballot(r.active && !direction_is_regular(r.dx, r.dy, r.dz)) == 0ull;
     unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
+    // direction classes: six compares voted one by one (direction_is_regular); the hard test runs only when some
+    // lane is not regular — about once per frame in the default scene
+    const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
+                                       ballot(fabsf(r.dy) >= 0x1p-60f) & ballot(fabsf(r.dy) <= 2.0f) &
+                                       ballot(fabsf(r.dz) >= 0x1p-60f) & ballot(fabsf(r.dz) <= 2.0f);
+    const bool all_regular = (alive & ~regular) == 0ull;
+    if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
+    const bool use_fast = FAST && all_regular;
     unsigned long long n_active = 0;
     if (COUNT) n_active = __popcll(alive);
     uint32_t i = 0;
