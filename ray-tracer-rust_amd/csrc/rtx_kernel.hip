@@ -119,6 +119,26 @@ struct ShadowRay {
     bool valid;          // the lane carries a ray (ray.active is consumed by the any-hit walk)
 };
 
+// (quo, rem) = ray number / and % the tile's divisor, see the callers; indices are small: 24-bit multiplies are full rate
+__device__ __forceinline__ ShadowRay shadow_ray_at(const float *__restrict__ l_hit, const float *__restrict__ l_light,
+                                                   bool valid, uint32_t quo, uint32_t rem, bool sample_major)
+{
+    ShadowRay s;
+    s.hp = sample_major ? rem : quo;     // compacted hit pixel
+    s.si = sample_major ? quo : rem;     // light sample within the batch
+    const float *h = l_hit + __umul24(kHitStride, s.hp);
+    const float *lp = l_light + __umul24(3u, s.si);
+    const float hx = h[0], hy = h[1], hz = h[2];
+    const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;                   // p - orig
+    const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                     // main.rs:202
+    float sx, sy, sz;
+    divide3_ieee(vx, vy, vz, dist_light, sx, sy, sz);                                 // Ray::new, main.rs:201 -> ray.rs:15
+    s.ray = make_ray(valid, hx, hy, hz, sx, sy, sz);
+    s.ray.limit = dist_light;
+    s.valid = valid;
+    return s;
+}
+
 __device__ __forceinline__ ShadowRay shadow_ray(const float *__restrict__ l_hit, const float *__restrict__ l_light,
                                                 uint32_t ray, uint32_t total, uint32_t div, bool sample_major)
 {
@@ -148,7 +168,7 @@ __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, f
     const LaneRay &r = s.ray;
     const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
     const bool lit = r.best_idx == kNone;       // main.rs:219-231 through any_hit: an index is kept only for an occluder
-    if (s.valid) l_res[s.hp * res_stride + s.si] = lit ? lnd : kOccluded;
+    if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? lnd : kOccluded;
 }
 
 // The same for a tile whose hit pixels are all grey (red == green == blue >= 0, equal running sums): the lane stores
@@ -157,11 +177,11 @@ __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, f
 __device__ __forceinline__ void shadow_result_grey(const float *__restrict__ l_hit, float *__restrict__ l_res,
                                                    uint32_t res_stride, const ShadowRay &s, float denom)
 {
-    const float *h = l_hit + kHitStride * s.hp;
+    const float *h = l_hit + __umul24(kHitStride, s.hp);
     const LaneRay &r = s.ray;
     const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
     const bool lit = r.best_idx == kNone;
-    if (s.valid) l_res[s.hp * res_stride + s.si] = lit ? (h[6] * lnd) / denom : kOccluded;
+    if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? (h[6] * lnd) / denom : kOccluded;
 }
 
 __device__ __forceinline__ void store_pixel(const DeviceScene &S, uint8_t *__restrict__ out, uint32_t px, uint32_t ly,
@@ -922,8 +942,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     const uint32_t total = n_hit * bc;
                     const uint32_t div = sample_major ? n_hit : bc;
                     const bool grey_tile = __builtin_amdgcn_readfirstlane(l_ctl[2]) != 0u;
+                    // (carrying the chunk's quotient and remainder in scalar registers, advanced by additions, removes
+                    //  the division per ray and was measured 3 % SLOWER on C2/C4, same box, interleaved runs)
                     for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
-                        ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
+                        const bool valid = c0 + lane < total;
+                        const uint32_t quo = (c0 + lane) / div;
+                        const uint32_t rem = (c0 + lane) - quo * div;
+                        ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
                         if (!ok && lane == 0) l_ctl[1] = 1u;
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
