@@ -15,9 +15,11 @@ output stays in HBM (torch tensor).  torch is plumbing here: device memory, stre
 torch.distributed.  Every ray is traced by the HIP kernel behind the C ABI (include/rtx.h).
 
 One JSON line on stdout (rank 0).  Besides the contract fields:
-  roofline      dominant kernel (trace_shade_kernel) against the HBM roof, as the contract asks;
-                algorithmic bytes defined in DESIGN.md §Roofline.  The kernel is FP32-VALU bound
-                (the whole scene is L2-resident), so "roofline_valu" is printed next to it.
+  roofline      dominant kernel (shade_tiles_kernel, the shading pass of a launch) against the HBM
+                roof, as the contract asks, timed by the library's HIP events around that pass on the
+                launch's stream (rtx_launch_timings); algorithmic bytes defined in DESIGN.md §Roofline.
+                The kernel is FP32-VALU bound (the whole scene is L2-resident), so "roofline_valu"
+                (whole launch) is printed next to it.
   cpu_baseline  the CPU oracle in faithful-BVH mode (= the reference's src/tracer algorithm,
                 "port") timed on this box's host cores on a bounded sample of the same frame.
 """
@@ -49,7 +51,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak (counts an FMA as 2 flop)
 FLOP_PER_TRI_TEST = 46         # full Möller–Trumbore path incl. the division
-FLOP_PER_BOX_TEST = 28         # conservative box test: 6 sub, 6 mul, 6 min/max, max3+min3 (4), add, fma (2), sub, 2 cmp
+FLOP_PER_BOX_TEST = 29         # conservative box test: 6 fma as 3 packed (12), 6 min/max, max3+min3 (4), add, fma (2), sub, mul, 2 cmp
+BYTES_PER_HIT_REC = 48         # p_hit, normal, colour: written by probe_kernel, read once by shade_tiles_kernel
 BYTES_PER_TRI_REC = 36         # v0,e1,e2 consumed per test
 BYTES_PER_BOX_REC = 24         # bmin,bmax
 BYTES_PER_PIXEL_IO = 11        # 8 B of the sample table + 3 B framebuffer
@@ -107,9 +110,9 @@ def reduce_counters(counters, world):
     return counters.cpu().tolist()
 
 
-def reduce_times(elapsed_s, kernel_s, world, device):
-    """MAX over ranks of the timed region and of the per-launch kernel time."""
-    tt = torch.tensor([elapsed_s, kernel_s], dtype=torch.float64, device=device)
+def reduce_times(values, world, device):
+    """MAX over ranks of the timed region and of the per-launch device times."""
+    tt = torch.tensor(list(values), dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -169,6 +172,7 @@ def main():
     torch.cuda.synchronize(dev)
     c = reduce_counters(counters, world)
     primary_hits, box_tests, tri_tests, node_visits, tri_visits = c[0], c[1], c[2], c[3], c[4]
+    sched_node_visits, sched_tri_visits = c[6], c[7]       # the scheduling pass's (primary rays') share of the fetches
     primary_rays = W * H * rtx.NB_RAY
     r_total = primary_rays + rtx.NB_LIGHT_SAMPLE * primary_hits
 
@@ -184,7 +188,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)   # this rank's launches
-    elapsed, kernel_s = reduce_times(elapsed, kernel_ms / 1e3, world, dev)
+    # the launch is two passes; the library brackets them with HIP events on the launch's stream (rtx_launch_timings):
+    # these are the timed region's own launches, newest last
+    sched_t, shade_t = scene.launch_timings(local_rank, min(args.steps, 64))
+    sched_ms = float(sched_t.mean()) if len(sched_t) else 0.0
+    shade_ms = float(shade_t.mean()) if len(shade_t) else kernel_ms
+    elapsed, kernel_s, sched_s, shade_s = reduce_times(
+        (elapsed, kernel_ms / 1e3, sched_ms / 1e3, shade_ms / 1e3), world, dev)
     ms_per_step = elapsed / args.steps * 1e3
 
     if args.save_png and world == 1:
@@ -194,9 +204,13 @@ def main():
 
     if rank == 0:
         mrays = r_total / (ms_per_step / 1e3) / 1e6
-        # roofline of the dominant kernel.  Per launch = per rank; counts are whole-frame sums, so divide by world.
-        alg_bytes = (tri_visits * BYTES_PER_TRI_REC + node_visits * BYTES_PER_BOX_REC + BYTES_PER_PIXEL_IO * W * H) / world
-        ach_gbs = alg_bytes / kernel_s / 1e9
+        # roofline of the dominant kernel = shade_tiles_kernel (the shading pass).  Per launch = per rank; counts are
+        # whole-frame sums, so divide by world.  Its algorithmic bytes: the records its walks consume, the hit record
+        # of every hit pixel (written by the scheduling pass, read once), the framebuffer.
+        launch_alg_bytes = (tri_visits * BYTES_PER_TRI_REC + node_visits * BYTES_PER_BOX_REC + BYTES_PER_PIXEL_IO * W * H) / world
+        alg_bytes = ((tri_visits - sched_tri_visits) * BYTES_PER_TRI_REC + (node_visits - sched_node_visits) * BYTES_PER_BOX_REC +
+                     BYTES_PER_HIT_REC * primary_hits + 3 * W * H) / world
+        ach_gbs = alg_bytes / shade_s / 1e9
         flops = (tri_tests * FLOP_PER_TRI_TEST + box_tests * FLOP_PER_BOX_TEST) / world
         ach_tf = flops / kernel_s / 1e12
         # SURVEY §8(d) brute-force-equivalent HBM-level bytes (G = 256 rays share a staged record)
@@ -205,7 +219,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch_n%d" % world)
+                tr = json.load(f).get(args.workload, {})
+                # of the dominant kernel when the profile separates the kernels of a launch, else of the launch
+                traffic = tr.get("hbm_bytes_shade_kernel_n%d" % world) or tr.get("hbm_bytes_per_launch_n%d" % world)
         pmc = None      # SQ counters of an earlier profiled run of the same workload (profiles/pmc_summary.json)
         ppath = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(ppath) and world == 1:
@@ -227,8 +243,14 @@ def main():
             "primary_mrays_per_s": round(primary_rays / (ms_per_step / 1e3) / 1e6, 3),
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "trace_shade_kernel", "kernel_ms": round(kernel_s * 1e3, 4),
+                         "kernel": "shade_tiles_kernel", "kernel_ms": round(shade_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "launch": {"passes": "probe_kernel + order_tiles_kernel (scheduling), shade_tiles_kernel + "
+                                              "reference_tiles_kernel (shading)",
+                                    "schedule_ms": round(sched_s * 1e3, 4), "shade_ms": round(shade_s * 1e3, 4),
+                                    "launch_ms": round(kernel_s * 1e3, 4),
+                                    "survey_8d_bytes": int(launch_alg_bytes),
+                                    "survey_8d_gbs": round(launch_alg_bytes / kernel_s / 1e9, 3)},
                          "note": "scene records %.2f MB (L2-resident when < 4 MB): the kernel is FP32-VALU / latency bound, "
                                  "see roofline_valu; survey_b_alg_* = SURVEY 8(d) brute-force-equivalent bytes"
                                  % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),

@@ -183,6 +183,15 @@ size_t   rtx_tiles_bytes(const RtxScene *scene, uint32_t first_tile, uint32_t ti
 int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t nrows, uint64_t *out,
                            size_t out_tiles, uint32_t *tiles_x, uint32_t *tiles_y);
 
+/* Diagnostics: device time of the most recent launches on `device`, oldest first.  A launch is two passes — the
+ * scheduling pass (probe_kernel + order_tiles_kernel: primary hits and the cost order of the tiles) and the
+ * shading pass (shade_tiles_kernel: shadow rays, ordered sums, RGB8) — bracketed by HIP events on the launch's
+ * stream; schedule_ms[i] / shade_ms[i] are their durations (schedule_ms = 0 for the single-kernel variants).
+ * Blocks until those launches have completed.  Returns how many launches were written (<= max_launches and
+ * <= RTX_TIMING_RING) or a negative RtxError. */
+#define RTX_TIMING_RING 64
+int rtx_launch_timings(RtxScene *scene, int device, int max_launches, float *schedule_ms, float *shade_ms);
+
 const char *rtx_strerror(int err);
 int rtx_last_hip_error(void);
 

@@ -47,6 +47,8 @@ struct DeviceState {
     rtx::StreamWorkspaceBytes ws_cap{};
     uint8_t *h_stage = nullptr;   // pinned
     size_t h_stage_cap = 0;
+    hipEvent_t ring[RTX_TIMING_RING][3] = {};   // launch start / end of the scheduling pass / launch end (rtx_launch_timings)
+    unsigned long long launches = 0;
 };
 
 // restores the caller's current device on scope exit
@@ -134,6 +136,8 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     RTX_HIP(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
     RTX_HIP(hipEventCreate(&st.ev0));
     RTX_HIP(hipEventCreate(&st.ev1));
+    for (auto &slot : st.ring)
+        for (hipEvent_t &e : slot) RTX_HIP(hipEventCreate(&e));
     st.uploaded = true;
     return RTX_OK;
 }
@@ -270,7 +274,8 @@ int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool co
         RTX_HIP(hipMemsetAsync(st.d_counters, 0, rtx::kNumCounters * sizeof(unsigned long long), st.stream));
     RTX_HIP(hipEventRecord(st.ev0, st.stream));
     RTX_HIP(rtx::launch_trace_shade(S, ts, st.d_out, st.d_redo, ws, count ? st.d_counters : nullptr, nullptr,
-                                    kernel_variant(), st.stream));
+                                    kernel_variant(), st.stream, st.ring[st.launches % RTX_TIMING_RING]));
+    if (ts.local_rows) ++st.launches;
     RTX_HIP(hipEventRecord(st.ev1, st.stream));
     return RTX_OK;
 }
@@ -331,6 +336,8 @@ void rtx_scene_destroy(RtxScene *scene)
         if (st.h_stage) (void)hipHostFree(st.h_stage);
         if (st.ev0) (void)hipEventDestroy(st.ev0);
         if (st.ev1) (void)hipEventDestroy(st.ev1);
+        for (auto &slot : st.ring)
+            for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
         if (st.stream) (void)hipStreamDestroy(st.stream);
     }
     delete scene;
@@ -495,7 +502,8 @@ int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, ui
     if ((rc = ensure_stream_ws(*st, S, ts, &ws)) != RTX_OK) return rc;
     RTX_HIP(rtx::launch_trace_shade(S, ts, static_cast<uint8_t *>(d_out_rgb), st->d_redo, ws,
                                     reinterpret_cast<unsigned long long *>(d_counters), nullptr, kernel_variant(),
-                                    static_cast<hipStream_t>(stream)));
+                                    static_cast<hipStream_t>(stream), st->ring[st->launches % RTX_TIMING_RING]));
+    if (ts.local_rows) ++st->launches;
     return RTX_OK;
 }
 
@@ -534,6 +542,26 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     for (size_t t = 0; t < n; ++t)   // the kernel keeps the earliest start as max(~t)
         out[rtx::kWaveProfWords * t + 2] = ~out[rtx::kWaveProfWords * t + 2];
     return RTX_OK;
+}
+
+int rtx_launch_timings(RtxScene *scene, int device, int max_launches, float *schedule_ms, float *shade_ms)
+{
+    if (!scene || max_launches < 0 || !schedule_ms || !shade_ms) return RTX_ERR_BAD_ARG;
+    DeviceState *st;
+    int rc = get_state(scene, device, &st);
+    if (rc != RTX_OK) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    DeviceGuard g(device);
+    RTX_HIP(g.status());
+    unsigned long long n = st->launches < RTX_TIMING_RING ? st->launches : RTX_TIMING_RING;
+    if (n > static_cast<unsigned long long>(max_launches)) n = static_cast<unsigned long long>(max_launches);
+    for (unsigned long long i = 0; i < n; ++i) {
+        hipEvent_t *ev = st->ring[(st->launches - n + i) % RTX_TIMING_RING];
+        RTX_HIP(hipEventSynchronize(ev[2]));
+        RTX_HIP(hipEventElapsedTime(&schedule_ms[i], ev[0], ev[1]));
+        RTX_HIP(hipEventElapsedTime(&shade_ms[i], ev[1], ev[2]));
+    }
+    return static_cast<int>(n);
 }
 
 int rtx_scene_light_points(const RtxScene *scene, float *out)

@@ -58,13 +58,14 @@ struct StreamWorkspace {
     float    *results;   // hits x nb_light: |n.l| or the "occluded" marker, per tile [sample][hit pixel]
     float    *acc;       // tiles x 64 x 3 running sums, only when nb_ray > 1
     uint32_t *ctr;       // hit count, chunk count, chunk cursor
-    uint32_t *buckets;   // probe pipeline: [0] = number of scheduled tiles, [kCostBuckets + i] = i-th tile, costliest first
+    uint32_t *buckets;   // probe pipeline: tile order by cost class (layout: order_tiles_kernel)
 };
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets; };
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);
 constexpr uint32_t kCostBuckets = 64u;
 
-// counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits
+// counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits,
+// 5 tiles re-rendered by reference_tiles_kernel, 6 / 7 the part of 3 / 4 spent in probe_kernel (primary rays)
 constexpr int kNumCounters = 8;
 
 // Light samples per LDS batch (results of one batch: 64 pixels x batch floats).
@@ -93,9 +94,12 @@ uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant);
 // [kQueueHeader]; trace_redo_bytes() is its size for a launch.  Reset and consumed inside the launch.
 constexpr uint32_t kQueueRedoCount = 0u, kQueueNextTile = 1u, kQueueHeader = 4u;
 size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts);
-// ws: workspace of the streamed pipeline (may be NULL: the fused kernel is used then)
+// ws: workspace of the streamed / probe pipelines (may be NULL: the fused kernel is used then)
+// phase_events: NULL or three events recorded on `stream`: launch start, end of the scheduling pass (probe + order;
+// = start for the single-kernel variants), launch end (rtx_launch_timings)
 hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                               const StreamWorkspace *ws, unsigned long long *d_counters,
-                              unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream);
+                              unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream,
+                              hipEvent_t *phase_events = nullptr);
 
 }  // namespace rtx

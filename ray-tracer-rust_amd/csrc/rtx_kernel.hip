@@ -815,57 +815,74 @@ __global__ void __launch_bounds__(64) probe_kernel(DeviceScene S, TileSpec ts, u
         const bool count_it = !(flags & 2u);
         const uint32_t key = (sky || (flags & 2u)) ? kNone : cost_class(cost);
         W.tiles[tile_id] = TileDesc{key, n_hit, flags, counted + (count_it ? n_hit : 0u)};
-        if (COUNT) flush_counters<COUNT>(counters, count_it ? (unsigned long long)n_hit : 0ull, wc);
+        if (COUNT) {
+            flush_counters<COUNT>(counters, count_it ? (unsigned long long)n_hit : 0ull, wc);
+            if (counters) {   // the scheduling pass's share of the record fetches (the probing walk is not counted)
+                atomicAdd(&counters[6], wc.node_visits);
+                atomicAdd(&counters[7], wc.tri_visits);
+            }
+        }
     }
 }
 
-// Counting sort of the scheduled tiles by cost class, costliest first: W.buckets[0] = number of tiles in the order,
-// W.buckets[kCostBuckets + i] = i-th tile.  One workgroup; equal classes within a wavefront are counted by one
-// lane (neighbouring tiles mostly share a class), so the LDS atomics stay few.
-__global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, StreamWorkspace W)
+// Counting sort of the scheduled tiles by cost class, costliest first.  Workspace words (W.buckets):
+//   [0] number of tiles in the order   [kOrderHist + k] tiles of class k (count_classes_kernel)
+//   [kOrderCursor + k] tiles of class k already placed   [kOrderList + i] the i-th tile
+// One workgroup per 1024 tiles: a class's position range starts where the costlier classes end (prefix over the
+// histogram); inside it each workgroup reserves a block with one atomic per class it holds, and its tiles take
+// consecutive slots.  Equal classes within a wavefront are counted by one lane — neighbouring tiles mostly share a
+// class — so the LDS atomics stay few.  (A single workgroup walking all tiles took 48 us of a 1.9 ms frame; one global
+// atomic per tile from probe_kernel — thousands on the few addresses of the common classes — added 90 us to it.)
+constexpr uint32_t kOrderHist = kCostBuckets, kOrderCursor = 2u * kCostBuckets, kOrderList = 3u * kCostBuckets;
+
+__global__ void __launch_bounds__(1024) count_classes_kernel(uint32_t n_tiles, StreamWorkspace W)
 {
-    __shared__ uint32_t count[kCostBuckets], base[kCostBuckets];
+    __shared__ uint32_t count[kCostBuckets];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < kCostBuckets) count[tid] = 0u;
     __syncthreads();
-    constexpr uint32_t kUnroll = 8u;   // keys fetched per thread before any is consumed: the loads overlap
-    for (int pass = 0; pass < 2; ++pass) {
-        for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u * kUnroll) {
-            uint32_t keys[kUnroll];
-#pragma unroll
-            for (uint32_t j = 0; j < kUnroll; ++j) {
-                const uint32_t i = i0 + j * 1024u + tid;
-                keys[j] = i < n_tiles ? W.tiles[i].first : kNone;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < kUnroll; ++j) {
-                const uint32_t i = i0 + j * 1024u + tid;
-                const uint32_t key = keys[j];
-                unsigned long long todo = ballot(key != kNone);
-                while (todo != 0ull) {
-                    const uint32_t k0 = __builtin_amdgcn_readfirstlane(__shfl(key, __ffsll((long long)todo) - 1));
-                    const unsigned long long same = ballot(key == k0);
-                    uint32_t off = 0u;
-                    if (lane == (uint32_t)(__ffsll((long long)same) - 1)) off = atomicAdd(&count[k0], (uint32_t)__popcll(same));
-                    off = __shfl(off, __ffsll((long long)same) - 1);
-                    if (pass == 1 && key == k0)
-                        W.buckets[kCostBuckets + base[k0] + off + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
-                    todo &= ~same;
-                }
-            }
-        }
-        __syncthreads();
-        if (pass == 0) {
-            if (tid == 0) {
-                uint32_t running = 0u;
-                for (uint32_t k = kCostBuckets; k-- != 0u;) { base[k] = running; running += count[k]; }
-                W.buckets[0] = running;
-            }
-            __syncthreads();
-            if (tid < kCostBuckets) count[tid] = 0u;
-            __syncthreads();
-        }
+    const uint32_t i = blockIdx.x * 1024u + tid;
+    const uint32_t key = i < n_tiles ? W.tiles[i].first : kNone;
+    unsigned long long todo = ballot(key != kNone);
+    while (todo != 0ull) {
+        const uint32_t k0 = __builtin_amdgcn_readfirstlane(__shfl(key, __ffsll((long long)todo) - 1));
+        const unsigned long long same = ballot(key == k0);
+        if (lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&count[k0], (uint32_t)__popcll(same));
+        todo &= ~same;
     }
+    __syncthreads();
+    if (tid < kCostBuckets && count[tid] != 0u) atomicAdd(&W.buckets[kOrderHist + tid], count[tid]);
+}
+
+__global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, StreamWorkspace W)
+{
+    __shared__ uint32_t count[kCostBuckets], start[kCostBuckets];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < kCostBuckets) count[tid] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024u + tid;
+    const uint32_t key = i < n_tiles ? W.tiles[i].first : kNone;
+    uint32_t slot = 0u;                       // this tile's position among the workgroup's tiles of its class
+    unsigned long long todo = ballot(key != kNone);
+    while (todo != 0ull) {
+        const uint32_t k0 = __builtin_amdgcn_readfirstlane(__shfl(key, __ffsll((long long)todo) - 1));
+        const unsigned long long same = ballot(key == k0);
+        uint32_t off = 0u;
+        if (lane == (uint32_t)(__ffsll((long long)same) - 1)) off = atomicAdd(&count[k0], (uint32_t)__popcll(same));
+        off = __shfl(off, __ffsll((long long)same) - 1);
+        if (key == k0) slot = off + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    __syncthreads();
+    if (tid < kCostBuckets) {
+        uint32_t before = 0u;                 // tiles of costlier classes
+        for (uint32_t k = tid + 1u; k < kCostBuckets; ++k) before += W.buckets[kOrderHist + k];
+        const uint32_t mine = count[tid];
+        start[tid] = before + (mine ? atomicAdd(&W.buckets[kOrderCursor + tid], mine) : 0u);
+        if (blockIdx.x == 0 && tid == 0) W.buckets[0] = before + W.buckets[kOrderHist];
+    }
+    __syncthreads();
+    if (key != kNone) W.buckets[kOrderList + start[key] + slot] = i;
 }
 
 // Without the primary phase the kernel fits 64 VGPRs (8 wavefronts per SIMD, 4 workgroups per CU) with three
@@ -900,7 +917,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         if (threadIdx.x == 0) {
             // q-th tile, costliest class first
             const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
-            l_ctl[3] = q < W.buckets[0] ? W.buckets[kCostBuckets + q] : kNone;
+            l_ctl[3] = q < W.buckets[0] ? W.buckets[3u * kCostBuckets + q] : kNone;
             l_ctl[1] = 0u;
         }
         __syncthreads();
@@ -1017,7 +1034,7 @@ namespace {
 
 template <bool COUNT, bool FAST, bool SPHERES>
 hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
-                        const StreamWorkspace &W, unsigned long long *d_counters, hipStream_t stream)
+                        const StreamWorkspace &W, unsigned long long *d_counters, hipStream_t stream, hipEvent_t *ev)
 {
     constexpr int NW = 8;
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
@@ -1042,9 +1059,12 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     if ((e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream)) != hipSuccess) return e;
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(W.buckets, 0, 3u * kCostBuckets * sizeof(uint32_t), stream)) != hipSuccess) return e;
         hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>), dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, n_tiles,
                            r, W, d_out, d_redo, d_counters);
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, W);
+        hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
+        if (ev && r == 0u && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;   // end of the scheduling pass
         hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
                            batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1173,29 +1193,28 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.results = streamed ? pixels * (S.nb_light ? S.nb_light : 1u) * sizeof(float) : 0u;
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);
-    b.buckets = probe ? (kCostBuckets + tiles) * sizeof(uint32_t) : 0u;
+    b.buckets = probe ? (3u * kCostBuckets + tiles) * sizeof(uint32_t) : 0u;
     return b;
 }
 
-hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
-                              const StreamWorkspace *ws, unsigned long long *d_counters,
-                              unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream)
+static hipError_t launch_dispatch(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
+                                  const StreamWorkspace *ws, unsigned long long *d_counters,
+                                  unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream, hipEvent_t *ev)
 {
-    if (ts.local_rows == 0) return hipSuccess;
     if ((variant & kVariantProbe) && ws && !d_wave_prof) {
         const bool fast = (variant & 1u) != 0u;
         if (S.n_spheres) {
             if (d_counters)
-                return fast ? launch_probe<true, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
-                            : launch_probe<true, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream);
-            return fast ? launch_probe<false, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream)
-                        : launch_probe<false, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+                return fast ? launch_probe<true, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev)
+                            : launch_probe<true, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev);
+            return fast ? launch_probe<false, true, true>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev)
+                        : launch_probe<false, false, true>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev);
         }
         if (d_counters)
-            return fast ? launch_probe<true, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream)
-                        : launch_probe<true, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
-        return fast ? launch_probe<false, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream)
-                    : launch_probe<false, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream);
+            return fast ? launch_probe<true, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev)
+                        : launch_probe<true, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev);
+        return fast ? launch_probe<false, true, false>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev)
+                    : launch_probe<false, false, false>(S, ts, d_out, d_redo, *ws, d_counters, stream, ev);
     }
     if ((variant & kVariantStream) && ws && !d_wave_prof && S.n_spheres == 0u) {   // the streamed kernels are triangle-only
         const bool fast = (variant & 1u) != 0u, packed = (variant & kVariantPacked) != 0u;
@@ -1215,6 +1234,22 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
     if (d_counters || d_wave_prof)
         return launch_select<true>(variant, S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
     return launch_select<false>(variant, S, ts, d_out, d_redo, d_counters, d_wave_prof, stream);
+}
+
+hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
+                              const StreamWorkspace *ws, unsigned long long *d_counters,
+                              unsigned long long *d_wave_prof, uint32_t variant, hipStream_t stream,
+                              hipEvent_t *phase_events)
+{
+    if (ts.local_rows == 0) return hipSuccess;
+    hipError_t e;
+    if (phase_events && (e = hipEventRecord(phase_events[0], stream)) != hipSuccess) return e;
+    const bool probe = (variant & kVariantProbe) && ws && !d_wave_prof;
+    if (phase_events && !probe && (e = hipEventRecord(phase_events[1], stream)) != hipSuccess) return e;
+    e = launch_dispatch(S, ts, d_out, d_redo, ws, d_counters, d_wave_prof, variant, stream, probe ? phase_events : nullptr);
+    if (e != hipSuccess) return e;
+    if (phase_events && (e = hipEventRecord(phase_events[2], stream)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 }  // namespace rtx

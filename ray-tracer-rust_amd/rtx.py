@@ -95,6 +95,7 @@ _SIGS = {
     "rtx_tiles_rows": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rtx_tiles_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rtx_debug_wave_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u32p, u32p]),
+    "rtx_launch_timings": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p]),
     "rtx_strerror": (C.c_char_p, [C.c_int]),
     "rtx_last_hip_error": (C.c_int, []),
     "rtx_scene_light_points": (C.c_int, [C.c_void_p, f32p]),
@@ -367,6 +368,15 @@ class Scene:
         _check(_lib.rtx_debug_wave_profile(self._h, device, row0, nrows, out.ctypes.data_as(u64p), tx.value * ty.value,
                                            C.byref(tx), C.byref(ty)), "rtx_debug_wave_profile")
         return out
+
+    def launch_timings(self, device=0, max_launches=64):
+        """Device milliseconds of the most recent launches, oldest first: (scheduling pass, shading pass) arrays."""
+        a = np.zeros(max_launches, np.float32)
+        b = np.zeros(max_launches, np.float32)
+        n = _lib.rtx_launch_timings(self._h, device, max_launches, _fp(a), _fp(b))
+        if n < 0:
+            raise RtxError(n, "rtx_launch_timings")
+        return a[:n], b[:n]
 
     def tiles_rows(self, first_tile, tile_stride, tile_rows):
         return _lib.rtx_tiles_rows(self._h, first_tile, tile_stride, tile_rows)

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Development tool: turn the CSVs of tools/collect_profiles.sh into the two small summaries bench.py reads,
+profiles/pmc_summary.json and profiles/traffic.json, and copy the evidence into profiles/<round>/.
+
+    python tools/summarise_profiles.py gpurun_out/prof_j c3 profiles/r01 j
+
+Counters are averaged over the dispatches of the uncounted kernels (template argument COUNT = false) of the
+profiled run; one launch = probe_kernel + count_classes_kernel + order_tiles_kernel + shade_tiles_kernel + reference_tiles_kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
+(MI355X_MICROARCH.md), so the x2 figure is used as the upper bound, WRITE_SIZE as it is.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+KERNELS = {"probe_kernel<false": "probe", "order_tiles_kernel": "order", "count_classes_kernel": "count", "shade_tiles_kernel<false": "shade",
+           "reference_tiles_kernel<false": "redo", "trace_shade_kernel<false": "fused"}
+N_SIMD = 1024               # 256 CUs x 4
+N_XCD = 8                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the dispatch = value / 8
+
+
+def which(name):
+    for k, v in KERNELS.items():
+        if ("rtx::" + k) in name:
+            return v
+    return None
+
+
+def load_counters(path):
+    """-> {kernel: {counter: mean value per dispatch}}, {kernel: mean duration ns}"""
+    acc, dur = {}, {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = which(r["Kernel_Name"])
+            if not k:
+                continue
+            acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            dur.setdefault(k, {})[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+    mdur = {k: sum(d.values()) / len(d) for k, d in dur.items()}
+    return mean, mdur
+
+
+def main():
+    src, wl, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(dst, exist_ok=True)
+    counters, durations = {}, {}
+    for i, path in enumerate(sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv")))):
+        c, d = load_counters(path)
+        for k, v in c.items():
+            counters.setdefault(k, {}).update(v)
+        for k, v in d.items():
+            durations.setdefault(k, []).append(v)
+        group = "_".join(sorted({n for v in c.values() for n in v}))[:60].lower()
+        shutil.copy(path, os.path.join(dst, "%s_pmc_%s_%s.csv" % (tag, wl, group)))
+    stats = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, wl)))
+    bench = os.path.join(src, "bench_%s.json" % wl)
+    if os.path.exists(bench):
+        shutil.copy(bench, os.path.join(dst, "%s_bench_%s.json" % (tag, wl)))
+
+    summary = {}
+    for k, c in counters.items():
+        if "SQ_INSTS_VALU" not in c:
+            continue
+        ms = sum(durations[k]) / len(durations[k]) / 1e6
+        e = {"kernel_ms_under_pmc": round(ms, 4),
+             "sq_insts_valu": c.get("SQ_INSTS_VALU"), "sq_insts_salu": c.get("SQ_INSTS_SALU"),
+             "sq_insts_smem": c.get("SQ_INSTS_SMEM"), "sq_insts_lds": c.get("SQ_INSTS_LDS"),
+             "sq_waves": c.get("SQ_WAVES"),
+             "sq_active_inst_valu_quadcycles": c.get("SQ_ACTIVE_INST_VALU"),
+             "sq_wait_any_quadcycles": c.get("SQ_WAIT_ANY"), "sq_wait_inst_any_quadcycles": c.get("SQ_WAIT_INST_ANY")}
+        if c.get("SQC_DCACHE_REQ"):
+            e["sqc_dcache_hit_rate"] = round(c.get("SQC_DCACHE_HITS", 0.0) / c["SQC_DCACHE_REQ"], 4)
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_INSTS_VALU"):
+            e["cycles_per_valu_inst"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3)
+            if c.get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE / 8 = shader-clock cycles of the dispatch; VALU busy = issue cycles / (cycles x SIMDs)
+                cycles = c["GRBM_GUI_ACTIVE"] / N_XCD
+                e["gpu_cycles"] = cycles
+                e["valu_busy"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * N_SIMD), 4)
+                e["shader_clock_ghz"] = round(cycles / (ms * 1e6), 3)
+        summary[k] = e
+    pmc_path = os.path.join(root, "profiles", "pmc_summary.json")
+    allp = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    allp["_comment"] = ("SQ counters per dispatch of the uncounted kernels (rocprofv3 --pmc, one MI355X, averaged over the "
+                        "profiled launches; sources profiles/<round>/<tag>_pmc_*.csv; tools/summarise_profiles.py). "
+                        "valu_busy = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); "
+                        "cycles_per_valu_inst = SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU.")
+    allp[wl] = {"source": "%s/%s_pmc_%s_*.csv" % (os.path.relpath(dst, root), tag, wl), "kernels": summary}
+    json.dump(allp, open(pmc_path, "w"), indent=1)
+
+    traffic_path = os.path.join(root, "profiles", "traffic.json")
+    allt = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+    fetch = {k: c.get("FETCH_SIZE") for k, c in counters.items() if c.get("FETCH_SIZE") is not None}
+    write = {k: c.get("WRITE_SIZE") for k, c in counters.items() if c.get("WRITE_SIZE") is not None}
+    if fetch and write:
+        launch = ("probe", "count", "order", "shade", "redo") if "shade" in fetch else ("fused", "redo")
+        f_kib = sum(fetch.get(k, 0.0) for k in launch)
+        w_kib = sum(write.get(k, 0.0) for k in launch)
+        allt["_comment"] = ("HBM bytes per launch (all kernels of one launch) from separate rocprofv3 --pmc FETCH_SIZE / "
+                            "--pmc WRITE_SIZE runs of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; KiB; "
+                            "FETCH_SIZE x2 (gfx950 under-reports wide reads by 2x: upper bound), WRITE_SIZE as reported.")
+        allt[wl] = {"fetch_size_kib_raw": {k: round(v, 1) for k, v in fetch.items()},
+                    "write_size_kib_raw": {k: round(v, 1) for k, v in write.items()},
+                    "hbm_bytes_per_launch_n1": int((2.0 * f_kib + w_kib) * 1024),
+                    "hbm_bytes_shade_kernel_n1": int((2.0 * fetch.get("shade", 0.0) + write.get("shade", 0.0)) * 1024),
+                    "source": "%s/%s_pmc_%s_{fetch_size,write_size}.csv" % (os.path.relpath(dst, root), tag, wl)}
+        json.dump(allt, open(traffic_path, "w"), indent=1)
+    print(json.dumps({"pmc": summary, "traffic": allt.get(wl)}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
