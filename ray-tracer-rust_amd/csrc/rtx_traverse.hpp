@@ -350,12 +350,22 @@ __device__ __forceinline__ unsigned long long slab_fast_fma_packed_mask(const No
     const float t_in = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(c.x, c.y));
     const float t_out = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(c.x, c.y));
     const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, r.slack0);
-    return ballot(!(t_in - t_out > slack)) & ballot(!(t_out < r.behind));   // a NaN can only accept
+    // "exit clearly behind the origin": against -slack instead of the ray constant -1.00001 E — slack >= E(1 - 2^-24),
+    // still eight times the absolute error term, and the negation is an operand modifier, not an instruction.
+    // (Tried and dropped, both measured slower on one box with interleaved runs although they remove six of the
+    //  sixteen vector instructions of this test: choosing each axis' near plane on the scalar unit for wavefronts whose
+    //  rays share an octant, +30 %; reading (near, far) from one of eight pre-swapped copies of the stream, +4..10 %.
+    //  The walk is a chain of dependent steps — scalar load, test, vote, branch — and at eight wavefronts per SIMD its
+    //  length costs as much as the instruction count.)
+    return ballot(!(t_in - t_out > slack)) & ballot(!(t_out < -slack));   // a NaN can only accept
 }
 
 #ifndef RTX_CULL_PACKED
 #define RTX_CULL_PACKED 1
 #endif
+// (Requesting both possible successors of a node as soon as the node is there, so that the scalar-memory latency
+//  runs under the test, was measured 25 % slower — same box, interleaved runs: the scalar unit and its cache, one per
+//  compute unit, are as loaded as the vector units here, 0.75 G scalar against 0.92 G vector instructions per frame.)
 
 __device__ __forceinline__ bool box_pass(bool use_fast, const NodeRec &n, const LaneRay &r)
 {
@@ -508,6 +518,35 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
 // does not depend on the tree.  Returns false (and traces nothing) when an active lane's direction is hard:
 // the tile is then re-rendered by reference_tiles_kernel.  A wavefront holding a soft direction uses the
 // exact slab test for this traversal (the multiply-based culling needs finite 1/d).
+// The walk itself, for one kind of box test (USE_FAST: the multiply-based conservative test, else the exact one).
+template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST>
+__device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                            const TriRec RTX_CONSTANT *__restrict__ tris,
+                                            const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
+                                            unsigned long long alive, unsigned long long n_active, WaveCounters &wc)
+{
+    uint32_t i = 0;
+    while (i < n_nodes) {
+        const NodeRec cur = load_node(nodes + i);
+        const bool leaf = (cur.info & kLeafFlag) != 0u;
+        const bool any = (box_mask(USE_FAST, cur, r) & alive) != 0ull;
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+        if (leaf && any) {
+            if (SPHERES && (cur.info & kSphereFlag))
+                leaf_spheres<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
+            else
+                leaf_triangles<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, alive, n_active, wc);
+            if (ANYHIT) {   // lanes that found an occluder have left the walk (r.active); so does a wavefront without lanes
+                alive = ballot(r.active);
+                if (alive == 0ull) break;
+                if (COUNT) n_active = __popcll(alive);
+            }
+        }
+        // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
+        i = (any || leaf) ? i + 1u : cur.link;
+    }
+}
+
 // SPHERES = false compiles the Sphere arm out: scenes without spheres (every BASELINE configuration) run the
 // triangle-only kernel, whose register allocation the extra arm would otherwise push into scratch.
 template <bool COUNT, bool FAST, bool SPHERES = false, bool ANYHIT = false>
@@ -527,26 +566,10 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     const bool use_fast = FAST && all_regular;
     unsigned long long n_active = 0;
     if (COUNT) n_active = __popcll(alive);
-    uint32_t i = 0;
-    while (i < n_nodes) {
-        const NodeRec cur = load_node(nodes + i);
-        const bool leaf = (cur.info & kLeafFlag) != 0u;
-        const bool any = (box_mask(use_fast, cur, r) & alive) != 0ull;
-        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
-        if (leaf && any) {
-            if (SPHERES && (cur.info & kSphereFlag))
-                leaf_spheres<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
-            else
-                leaf_triangles<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, alive, n_active, wc);
-            if (ANYHIT) {   // lanes that found an occluder have left the walk (r.active); so does a wavefront without lanes
-                alive = ballot(r.active);
-                if (alive == 0ull) break;
-                if (COUNT) n_active = __popcll(alive);
-            }
-        }
-        // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
-        i = (any || leaf) ? i + 1u : cur.link;
-    }
+    // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
+    // the choice inside the loop every node paid two more taken branches on the scalar unit)
+    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc);
+    else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc);
     return true;
 }
 
