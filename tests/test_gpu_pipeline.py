@@ -1,0 +1,105 @@
+"""GPU tests of the launch structure (probe_kernel -> count/order -> shade_tiles_kernel -> reference_tiles_kernel):
+the corners where the passes hand work to each other.  Results are still checked against the oracle."""
+import importlib
+
+import numpy as np
+import pytest
+
+from test_host_spheres import mixed_scene
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def rtx():
+    mod = importlib.import_module("ray-tracer-rust_amd")
+    assert mod.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return mod
+
+
+AXIS = dict(eye=(0.0, 0.0, 0.0), look_at=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), distance=24.0,
+            light_tri=(-2.0, 9.0, -3.0, 2.0, 9.0, -3.0, 0.0, 9.0, 1.0))
+
+
+def soup(seed, n=260):
+    rng = np.random.default_rng(seed)
+    v = rng.integers(-6, 7, size=(n, 3, 3)).astype(F)
+    v[..., 2] -= 14.0
+    e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    v = v[np.linalg.norm(np.cross(e1, e2), axis=1) > 1e-3]
+    return v.reshape(-1, 9), rng.uniform(0.2, 1.0, size=(len(v), 3)).astype(F)
+
+
+@pytest.mark.parametrize("nb_ray,nb_light", [(2, 12), (3, 5)])
+def test_several_primary_rays_with_tiles_queued_for_the_reference_walk(rtx, orc, nb_ray, nb_light):
+    """nb_ray > 1 and an all-zero sample table: every primary ray of the centre row/column has a zero direction
+    component, so the scheduling pass queues those tiles at r = 0 and must keep them queued (once) at r = 1, 2; the
+    running sums of the other tiles travel through HBM between the passes; hit counts are the oracle's."""
+    tris, rgb = soup(41)
+    T = np.zeros((4096, 2), F)
+    W = H = 40
+    ref, ost = orc.Scene(W, H, tris, rgb, T, nb_ray=nb_ray, nb_light_sample=nb_light, **AXIS).render_rows(mode=orc.MODE_BVH)
+    with rtx.Scene(W, H, tris, rgb, T, nb_ray=nb_ray, nb_light_sample=nb_light, **AXIS) as s:
+        img, st = s.render_rows(stats=True)
+        again = s.render_rows()                               # the workspace is reused by the next launch
+    assert st["redo_tiles"] > 0 and st["redo_tiles"] <= (W // 8) * (H // 8)       # queued once, not once per ray
+    assert st["primary_rays"] == nb_ray * W * H and st["primary_hits"] == ost["primary_hits"]
+    assert np.array_equal(img, ref) and np.array_equal(again, ref)
+
+
+def test_light_batches_and_partial_tiles(rtx, orc, samples_seeded):
+    """More light samples than one LDS batch holds (128) and a frame whose edge tiles are partial in both directions."""
+    tris, rgb = soup(42, 120)
+    W, H = 37, 21
+    kw = dict(AXIS, nb_light_sample=150)
+    ref, ost = orc.Scene(W, H, tris, rgb, samples_seeded, **kw).render_rows(mode=orc.MODE_BVH)
+    with rtx.Scene(W, H, tris, rgb, samples_seeded, **kw) as s:
+        img, st = s.render_rows(stats=True)
+        rows = np.concatenate([s.render_rows(0, 5), s.render_rows(5, 16)])          # launches that start off the tile grid
+    assert st["primary_hits"] == ost["primary_hits"]
+    assert np.array_equal(img, ref) and np.array_equal(rows, ref)
+
+
+def test_no_light_samples_and_empty_scene_view(rtx, orc, samples_seeded):
+    """nb_light_sample = 0 (every hit pixel stays black: the scheduling pass has nothing to probe) and a camera that
+    sees nothing (every tile is finished by the scheduling pass, the shading pass has no tile to pull)."""
+    tris, rgb = soup(43, 60)
+    W = H = 24
+    with rtx.Scene(W, H, tris, rgb, samples_seeded, **dict(AXIS, nb_light_sample=0)) as s:
+        img, st = s.render_rows(stats=True)
+    assert st["primary_hits"] > 0 and st["shadow_rays"] == 0 and not img.any()
+    away = dict(AXIS, look_at=(0.0, 0.0, 1.0), nb_light_sample=8)
+    ref, ost = orc.Scene(W, H, tris, rgb, samples_seeded, **away).render_rows(mode=orc.MODE_BVH)
+    with rtx.Scene(W, H, tris, rgb, samples_seeded, **away) as s:
+        img, st = s.render_rows(stats=True)
+    assert ost["primary_hits"] == 0 == st["primary_hits"] and np.array_equal(img, ref)
+
+
+def test_mixed_arms_several_primary_rays_zero_table(rtx, orc):
+    tris, rgb, spheres, srgb, kinds = mixed_scene(np.random.default_rng(44), 150, 40)
+    T = np.zeros((4096, 2), F)
+    kw = dict(AXIS, nb_ray=2, nb_light_sample=10)
+    W = H = 32
+    ref, ost = orc.Scene(W, H, tris, rgb, T, spheres=spheres, sphere_rgb=srgb, kinds=kinds, **kw).render_rows(mode=orc.MODE_BVH)
+    with rtx.Scene(W, H, tris, rgb, T, spheres=spheres, sphere_rgb=srgb, kinds=kinds, **kw) as s:
+        img, st = s.render_rows(stats=True)
+    assert st["primary_hits"] == ost["primary_hits"] and st["redo_tiles"] > 0
+    assert np.array_equal(img, ref)
+
+
+def test_launch_timings(rtx, samples_seeded):
+    """rtx_launch_timings: one (scheduling, shading) pair per launch, oldest first, bounded by the ring."""
+    tris, rgb = soup(45)
+    with rtx.Scene(64, 64, tris, rgb, samples_seeded, **dict(AXIS, nb_light_sample=16)) as s:
+        a, b = s.launch_timings()
+        assert len(a) == 0 and len(b) == 0
+        for _ in range(3):
+            s.render_rows()
+        sched, shade = s.launch_timings()
+        assert len(sched) == len(shade) == 3
+        assert (shade > 0).all() and (sched >= 0).all() and (sched + shade < 1000.0).all()
+        assert len(s.launch_timings(max_launches=2)[0]) == 2
+        for _ in range(70):
+            s.render_rows(0, 8)
+        assert len(s.launch_timings(max_launches=100)[0]) == 64          # RTX_TIMING_RING
