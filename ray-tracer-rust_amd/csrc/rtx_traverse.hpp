@@ -518,6 +518,28 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
 // does not depend on the tree.  Returns false (and traces nothing) when an active lane's direction is hard:
 // the tile is then re-rendered by reference_tiles_kernel.  A wavefront holding a soft direction uses the
 // exact slab test for this traversal (the multiply-based culling needs finite 1/d).
+// The same fetch with the record's byte offset in a scalar register (s_load_dwordx8 sdst, sbase, soffset): the compiler
+// only emits the form with a 64-bit address it first assembles with four scalar instructions, and the scalar unit —
+// one per compute unit — is as loaded as the vector units in this loop.  The wait is part of the statement: the
+// compiler does not count a load it has not issued itself.
+#ifndef RTX_ASM_NODE_LOAD
+#define RTX_ASM_NODE_LOAD 1
+#endif
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ NodeRec load_node_at(const NodeRec RTX_CONSTANT *base, uint32_t index)
+{
+    u32x8 v;
+    const uint32_t byte_offset = index << 5;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byte_offset));
+    NodeRec r;   // NodeDev order, see load_node
+    r.bmin[0] = __uint_as_float(v[0]); r.bmin[1] = __uint_as_float(v[1]);
+    r.bmax[0] = __uint_as_float(v[2]); r.bmax[1] = __uint_as_float(v[3]);
+    r.bmin[2] = __uint_as_float(v[4]); r.bmax[2] = __uint_as_float(v[5]);
+    r.link = v[6];
+    r.info = v[7];
+    return r;
+}
+
 // The walk itself, for one kind of box test (USE_FAST: the multiply-based conservative test, else the exact one).
 template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST>
 __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
@@ -527,7 +549,11 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
 {
     uint32_t i = 0;
     while (i < n_nodes) {
+#if RTX_ASM_NODE_LOAD
+        const NodeRec cur = load_node_at(nodes, i);
+#else
         const NodeRec cur = load_node(nodes + i);
+#endif
         const bool leaf = (cur.info & kLeafFlag) != 0u;
         const bool any = (box_mask(USE_FAST, cur, r) & alive) != 0ull;
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
