@@ -434,6 +434,26 @@ __device__ __forceinline__ void divide3_ieee(float ax, float ay, float az, float
     q0 = az * y; r0 = __builtin_fmaf(-b, q0, az); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, az); qz = __builtin_fmaf(r1, y, q1);
 }
 
+// A whole 64-byte primitive record with one scalar load, its byte offset in a scalar register (see load_node_at).
+#ifndef RTX_ASM_TRI_LOAD
+#define RTX_ASM_TRI_LOAD 1
+#endif
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ TriRec load_tri_at(const TriRec RTX_CONSTANT *base, uint32_t index)
+{
+    u32x16 v;
+    const uint32_t byte_offset = index << 6;
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byte_offset));
+    TriRec t;
+    t.v0[0] = __uint_as_float(v[0]); t.v0[1] = __uint_as_float(v[1]); t.v0[2] = __uint_as_float(v[2]);
+    t.e1[0] = __uint_as_float(v[3]); t.e1[1] = __uint_as_float(v[4]); t.e1[2] = __uint_as_float(v[5]);
+    t.e2[0] = __uint_as_float(v[6]); t.e2[1] = __uint_as_float(v[7]); t.e2[2] = __uint_as_float(v[8]);
+    t.bmin[0] = __uint_as_float(v[9]); t.bmin[1] = __uint_as_float(v[10]); t.bmin[2] = __uint_as_float(v[11]);
+    t.bmax[0] = __uint_as_float(v[12]); t.bmax[1] = __uint_as_float(v[13]); t.bmax[2] = __uint_as_float(v[14]);
+    t.idx = v[15];
+    return t;
+}
+
 template <bool COUNT, bool ANYHIT = false>
 __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
                                                const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
@@ -441,7 +461,12 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
                                                WaveCounters &wc)
 {
     for (uint32_t k = 0; k < count; ++k) {
+#if RTX_ASM_TRI_LOAD
+        const TriRec rec = load_tri_at(tris, first + k);
+        const TriRec *tr = &rec;
+#else
         const TriRec RTX_CONSTANT *tr = tris + (first + k);
+#endif
         const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
         const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
         const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
