@@ -79,18 +79,22 @@ def main():
             e["sqc_dcache_hit_rate"] = round(c.get("SQC_DCACHE_HITS", 0.0) / c["SQC_DCACHE_REQ"], 4)
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_INSTS_VALU"):
             e["cycles_per_valu_inst"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 3)
+            # against the peak engine clock: a lower bound of the busy fraction (the clock under load is <= 2.4 GHz)
+            e["valu_busy_at_2p4_ghz"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (ms * 1e-3 * 2.4e9 * N_SIMD), 4)
+            if c.get("SQ_ACTIVE_INST_SCA"):
+                e["sq_active_inst_sca"] = c["SQ_ACTIVE_INST_SCA"]
             if c.get("GRBM_GUI_ACTIVE"):
                 # GRBM_GUI_ACTIVE / 8 = shader-clock cycles of the dispatch; VALU busy = issue cycles / (cycles x SIMDs)
                 cycles = c["GRBM_GUI_ACTIVE"] / N_XCD
                 e["gpu_cycles"] = cycles
-                e["valu_busy"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * N_SIMD), 4)
+                e["valu_busy_grbm"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * N_SIMD), 4)   # GRBM pass ran separately
                 e["shader_clock_ghz"] = round(cycles / (ms * 1e6), 3)
         summary[k] = e
     pmc_path = os.path.join(root, "profiles", "pmc_summary.json")
     allp = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
     allp["_comment"] = ("SQ counters per dispatch of the uncounted kernels (rocprofv3 --pmc, one MI355X, averaged over the "
                         "profiled launches; sources profiles/<round>/<tag>_pmc_*.csv; tools/summarise_profiles.py). "
-                        "valu_busy = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); "
+                        "valu_busy_at_2p4_ghz = SQ_ACTIVE_INST_VALU*4 / (duration * 2.4 GHz * 1024 SIMDs), a lower bound; "
                         "cycles_per_valu_inst = SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU.")
     allp[wl] = {"source": "%s/%s_pmc_%s_*.csv" % (os.path.relpath(dst, root), tag, wl), "kernels": summary}
     json.dump(allp, open(pmc_path, "w"), indent=1)
