@@ -130,9 +130,8 @@ __device__ __forceinline__ ShadowRay shadow_ray_at(const float *__restrict__ l_h
     const float *lp = l_light + __umul24(3u, s.si);
     const float hx = h[0], hy = h[1], hz = h[2];
     const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;                   // p - orig
-    const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);                     // main.rs:202
-    float sx, sy, sz;
-    divide3_ieee(vx, vy, vz, dist_light, sx, sy, sz);                                 // Ray::new, main.rs:201 -> ray.rs:15
+    float dist_light, sx, sy, sz;
+    length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);                         // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
     s.ray = make_ray(valid, hx, hy, hz, sx, sy, sz);
     s.ray.limit = dist_light;
     s.valid = valid;
@@ -961,10 +960,15 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     const bool grey_tile = __builtin_amdgcn_readfirstlane(l_ctl[2]) != 0u;
                     // (carrying the chunk's quotient and remainder in scalar registers, advanced by additions, removes
                     //  the division per ray and was measured 3 % SLOWER on C2/C4, same box, interleaved runs)
+                    // Ray number / div in six full-rate instructions: trunc((ray + 0.5) * fl(1/div)) is the exact quotient
+                    // for ray < 2^22 — the product's error, 2^-23 (ray + 0.5)/div, stays below the 0.5/div that separates
+                    // it from the next integer (checked exhaustively for the domain, ray < 8320, div <= 128).  The
+                    // general 32-bit division costs three quarter-rate multiplies and a dozen more instructions.
+                    const float inv_div = 1.0f / (float)div;
                     for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                         const bool valid = c0 + lane < total;
-                        const uint32_t quo = (c0 + lane) / div;
-                        const uint32_t rem = (c0 + lane) - quo * div;
+                        const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
+                        const uint32_t rem = (c0 + lane) - __umul24(quo, div);
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
                         if (!ok && lane == 0) l_ctl[1] = 1u;

@@ -434,6 +434,37 @@ __device__ __forceinline__ void divide3_ieee(float ax, float ay, float az, float
     q0 = az * y; r0 = __builtin_fmaf(-b, q0, az); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, az); qz = __builtin_fmaf(r1, y, q1);
 }
 
+// Length of (vx, vy, vz) and the unit vector along it, both bit for bit what sqrtf and three IEEE divisions give
+// (main.rs:201-202, ray.rs:15), for wavefronts whose lanes all lie in the verified ranges:
+//   length   v_sqrt_f32 corrected by at most one ulp with two fused residuals — the compiler's own correctly rounded
+//            square root without its range scaling and special cases; equal to sqrtf for every binary32 in
+//            [2^-90, 2^100] (tools/sqrt_exhaustive.hip: 1.6e9 inputs, 0 differences)
+//   quotient divide3_ieee's shared-reciprocal steps; its ranges follow from 2^-45 <= |component| and x <= 2^100
+// A wavefront with a lane outside (a zero component, for one) takes sqrtf and the divisions.
+__device__ __forceinline__ void length_and_direction(float vx, float vy, float vz, float &len, float &dx, float &dy,
+                                                     float &dz)
+{
+    const float x = vx * vx + vy * vy + vz * vz;
+    const float smallest = fminf(fminf(fabsf(vx), fabsf(vy)), fabsf(vz));
+    if ((ballot(smallest >= 0x1p-45f) & ballot(x <= 0x1p100f)) != ballot(true)) {
+        len = sqrtf(x);
+        dx = vx / len; dy = vy / len; dz = vz / len;
+        return;
+    }
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float b = rm <= 0.0f ? sm : s;
+    b = rp > 0.0f ? sp : b;
+    len = b;
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float y = __builtin_fmaf(y0, __builtin_fmaf(-b, y0, 1.0f), y0);
+    float q0, r0, q1, r1;
+    q0 = vx * y; r0 = __builtin_fmaf(-b, q0, vx); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, vx); dx = __builtin_fmaf(r1, y, q1);
+    q0 = vy * y; r0 = __builtin_fmaf(-b, q0, vy); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, vy); dy = __builtin_fmaf(r1, y, q1);
+    q0 = vz * y; r0 = __builtin_fmaf(-b, q0, vz); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, vz); dz = __builtin_fmaf(r1, y, q1);
+}
+
 // A whole 64-byte primitive record with one scalar load, its byte offset in a scalar register (see load_node_at).
 #ifndef RTX_ASM_TRI_LOAD
 #define RTX_ASM_TRI_LOAD 1
