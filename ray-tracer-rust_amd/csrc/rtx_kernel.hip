@@ -4,6 +4,12 @@
 // (src/main.rs:151-240, src/tracer/**); citations are path:line in that repository.
 // The traversal itself is in rtx_traverse.hpp.
 //
+// The shipped launch (launch_probe, further down) is two passes: probe_kernel + count_classes_kernel +
+// order_tiles_kernel find every tile's primary hits and order the tiles by estimated cost; shade_tiles_kernel —
+// phases 2 and 3 of the kernel described next, fed from the hit records the first pass left in HBM — renders them
+// costliest first.  The single-kernel form below remains selectable (RTX_VARIANT=3) and is what the per-tile
+// diagnostics instrument.
+//
 // trace_shade_kernel — one workgroup per 8x8 pixel tile, NW wavefronts per workgroup
 //   phase 1  one work-item per pixel: wave 0 generates the 64 primary rays of the tile and finds
 //            their closest hits; hit pixels are compacted and their hit point + normal go to LDS.

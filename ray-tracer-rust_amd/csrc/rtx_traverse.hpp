@@ -11,7 +11,8 @@
 //   counts only if the ray also passes that triangle's own AABB with the reference's exact slab
 //   arithmetic (bvh.rs:52) and t >= 1.0 (bvh.rs:64-67).  Because the reference never prunes by
 //   distance, every node whose box passes is visited here too; the result is the minimum over
-//   the same candidate set.
+//   the same candidate set.  Shadow rays (any_hit) stop at the first candidate that fails the
+//   reference's "lit" test — equivalent to testing the closest one, see candidate_occludes.
 //
 //   Inner-node culling only has to be CONSERVATIVE (never reject a box the exact test accepts):
 //   slab_fast() replaces the six IEEE divisions by multiplications with 1/d and widens the
