@@ -103,3 +103,36 @@ def test_launch_timings(rtx, samples_seeded):
         for _ in range(70):
             s.render_rows(0, 8)
         assert len(s.launch_timings(max_launches=100)[0]) == 64          # RTX_TIMING_RING
+
+
+def test_every_tile_of_a_4096_square_frame_is_rendered_exactly_once(rtx, orc, samples_seeded):
+    """BASELINE configs[3] at full size (262,144 tiles: 256 workgroups of the count / order kernels): the frame is
+    rendered into two buffers pre-filled with different bytes — a tile the cost-ordered schedule skipped would keep
+    the filler, a tile rendered twice could not be told, so the launch's own hit count is checked against the
+    number of non-black pixels too — and three one-row bands are compared with the oracle."""
+    import os
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    W = H = 4096
+    frames = []
+    with rtx.default_scene([os.path.join(root, "models", "big_bunny.obj")], W, H, samples_seeded) as s:
+        nbytes = s.tiles_bytes(0, 1, 8)
+        assert nbytes == W * H * 3
+        ctr = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        for filler in (0xAA, 0x55):
+            buf = torch.full((nbytes,), filler, dtype=torch.uint8, device="cuda:0")
+            s.render_tiles_device(0, 0, 1, 8, buf.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream,
+                                  ctr.data_ptr() if filler == 0xAA else None)
+            torch.cuda.synchronize()
+            frames.append(buf.cpu().numpy().reshape(H, W, 3))
+        hits = int(ctr[0])
+    assert np.array_equal(frames[0], frames[1])
+    # sky pixels are exactly black; so are hit pixels in full shadow, a minority
+    lit = int((frames[0].reshape(-1, 3).max(axis=1) > 0).sum())
+    assert 0.5 * hits < lit <= hits
+    osc = orc.default_scene(["big_bunny.obj"], W, H, samples_seeded)
+    for row in (2000, 2100, 4095):             # across the mesh, across its shadow, the last row
+        ref, _ = osc.render_rows(row, 1, mode=orc.MODE_BVH)
+        assert np.array_equal(frames[0][row:row + 1], ref), "row %d" % row
