@@ -361,8 +361,12 @@ __device__ __forceinline__ unsigned long long slab_fast_fma_packed_mask(const No
     return ballot(!(t_in - t_out > slack)) & ballot(!(t_out < -slack));   // a NaN can only accept
 }
 
+// Packed f32 arithmetic does not pay in this kernel: with six single v_fma_f32 the frame is 4.5 % FASTER than with the
+// three v_pk_fma_f32 (same box, interleaved runs; 19 instead of 16 vector instructions per node), and packing the
+// cross and dot products of the triangle test — by the compiler (SLP) or by hand over a pair-ordered record — made it
+// 7-9 % slower.  The packed forms stay selectable.
 #ifndef RTX_CULL_PACKED
-#define RTX_CULL_PACKED 1
+#define RTX_CULL_PACKED 0
 #endif
 // (Requesting both possible successors of a node as soon as the node is there, so that the scalar-memory latency
 //  runs under the test, was measured 25 % slower — same box, interleaved runs: the scalar unit and its cache, one per
@@ -388,6 +392,16 @@ __device__ __forceinline__ unsigned long long box_mask(bool use_fast, const Node
 {
 #if RTX_CULL_FMA && RTX_CULL_PACKED
     if (use_fast) return slab_fast_fma_packed_mask(n, r);
+#elif RTX_CULL_FMA
+    if (use_fast) {   // the same with six single fused multiply-adds
+        const float ax = __builtin_fmaf(n.bmin[0], r.ix, r.nx), bx = __builtin_fmaf(n.bmax[0], r.ix, r.nx);
+        const float ay = __builtin_fmaf(n.bmin[1], r.iy, r.ny), by = __builtin_fmaf(n.bmax[1], r.iy, r.ny);
+        const float az = __builtin_fmaf(n.bmin[2], r.iz, r.nz), bz = __builtin_fmaf(n.bmax[2], r.iz, r.nz);
+        const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const float slack = __builtin_fmaf(fabsf(t_in) + fabsf(t_out), 0x1p-20f, r.slack0);
+        return ballot(!(t_in - t_out > slack)) & ballot(!(t_out < -slack));
+    }
 #endif
     return ballot(box_pass(use_fast, n, r));
 }
