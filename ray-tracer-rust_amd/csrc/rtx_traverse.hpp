@@ -596,6 +596,9 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
 #ifndef RTX_ASM_NODE_LOAD
 #define RTX_ASM_NODE_LOAD 1
 #endif
+#ifndef RTX_SKIP_ROOT_TEST
+#define RTX_SKIP_ROOT_TEST 1
+#endif
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ NodeRec load_node_at(const NodeRec RTX_CONSTANT *base, uint32_t index)
 {
@@ -618,7 +621,10 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
                                             unsigned long long alive, unsigned long long n_active, WaveCounters &wc)
 {
-    uint32_t i = 0;
+    // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
+    // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
+    // DESIGN.md) every enclosing box, the root's included.  One node in thirteen on the default scene.
+    uint32_t i = (RTX_SKIP_ROOT_TEST && n_nodes > 1u) ? 1u : 0u;
     while (i < n_nodes) {
 #if RTX_ASM_NODE_LOAD
         const NodeRec cur = load_node_at(nodes, i);
