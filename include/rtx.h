@@ -129,7 +129,7 @@ typedef struct RtxSceneInfo {
     uint32_t n_tris, n_nodes, n_leaves, max_leaf_tris, depth;
     uint32_t n_light_points;
     uint32_t n_ref_nodes;       /* records of the reference-tree stream (0 = not built) */
-    uint32_t reserved;
+    uint32_t n_global;      /* triangles as large as the scene (the ground): tested by every walk up front, outside the tree */
     uint64_t node_bytes, tri_bytes, shade_bytes, sample_bytes;
 } RtxSceneInfo;
 

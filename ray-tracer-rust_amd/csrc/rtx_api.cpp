@@ -161,6 +161,7 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     S.nb_ray = p.nb_ray;
     S.nb_light = p.nb_light_sample;
     S.n_spheres = p.n_spheres;
+    S.n_global = p.n_global;
     std::memcpy(S.eye, p.eye, 12);
     std::memcpy(S.cu, p.cam_u, 12);
     std::memcpy(S.cv, p.cam_v, 12);
@@ -354,7 +355,7 @@ int rtx_scene_info(const RtxScene *scene, RtxSceneInfo *info)
     info->depth = p.depth;
     info->n_light_points = p.nb_ray * p.nb_light_sample;
     info->n_ref_nodes = static_cast<uint32_t>(p.ref_nodes.size());
-    info->reserved = 0;
+    info->n_global = p.n_global;
     info->node_bytes = p.nodes.size() * sizeof(rtx::NodeRec);
     info->tri_bytes = p.tris.size() * sizeof(rtx::TriRec);
     info->shade_bytes = p.shade.size() * sizeof(rtx::ShadeRec);

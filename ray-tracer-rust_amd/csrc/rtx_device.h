@@ -22,6 +22,7 @@ struct DeviceScene {
     uint32_t n_nodes, n_ref_nodes, n_samples;
     uint32_t width, height;
     uint32_t nb_ray, nb_light;
+    uint32_t n_global;             // > 0: primitive records [0, n_global) are tested by every walk up front, the tree proper starts at node 2
     uint32_t n_spheres;            // > 0: some leaves carry kSphereFlag: the fused kernel with the Sphere arm compiled in is launched
     float eye[3], cu[3], cv[3], cw[3];
     float distance;

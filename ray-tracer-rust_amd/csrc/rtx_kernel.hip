@@ -277,7 +277,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             if (COUNT) t_mark = wall_clock64();
             primary_ray(S, in_frame, px, py, r, dx, dy, dz);
             LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
-            const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
+            const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
             const float t = pr.best_t;
             const uint32_t idx = pr.best_idx;
             const bool hit = in_frame && idx != kNone;
@@ -327,7 +327,7 @@ trace_shade_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 //  slower, 4.3 vs 3.7 ms on C3: it needs ~105 VGPRs, and resident wavefronts hide more latency)
                 for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                     ShadowRay sr = shadow_ray(l_hit, l_light, c0 + lane, total, div, sample_major);
-                    const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
+                    const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global);   // main.rs:204
                     if (!ok && lane == 0) l_ctl[1] = 1u;
                     shadow_result(l_hit, l_res, res_stride, sr);
                 }
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(64) probe_kernel(DeviceScene S, TileSpec ts, u
     float dx, dy, dz;
     primary_ray(S, in_frame, px, py, r, dx, dy, dz);
     LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
-    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc);   // main.rs:187
+    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
     const bool hit = ok && in_frame && pr.best_idx != kNone;
     const unsigned long long hit_mask = ballot(hit);
     const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
@@ -799,7 +799,7 @@ __global__ void __launch_bounds__(64) probe_kernel(DeviceScene S, TileSpec ts, u
         LaneRay sr = make_ray(hit, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);
         sr.limit = dist_light;
         WaveCounters probe;
-        (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe);
+        (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
         const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
         cost = (probe.node_visits + probe.tri_visits + 1ull) * n_chunks;
     }
@@ -976,7 +976,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
                         const uint32_t rem = (c0 + lane) - __umul24(quo, div);
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
-                        const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc);   // main.rs:204
+                        const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global);   // main.rs:204
                         if (!ok && lane == 0) l_ctl[1] = 1u;
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
                         else shadow_result(l_hit, l_res, res_stride, sr);

@@ -619,12 +619,24 @@ template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST>
 __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
-                                            unsigned long long alive, unsigned long long n_active, WaveCounters &wc)
+                                            unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
+                                            uint32_t n_global)
 {
     // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
     // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
     // DESIGN.md) every enclosing box, the root's included.  One node in thirteen on the default scene.
     uint32_t i = (RTX_SKIP_ROOT_TEST && n_nodes > 1u) ? 1u : 0u;
+    if (RTX_SKIP_ROOT_TEST && n_global != 0u) {
+        // the "global" triangles (scene_prep.cpp: as large as the scene, i.e. the ground) sit in the leaf at node 1:
+        // tested here without its box test, then the walk starts at the root of the tree proper
+        leaf_triangles<COUNT, ANYHIT>(tris, shade, 0u, n_global, r, alive, n_active, wc);
+        if (ANYHIT) {
+            alive = ballot(r.active);
+            if (alive == 0ull) return;
+            if (COUNT) n_active = __popcll(alive);
+        }
+        i = 2u;
+    }
     while (i < n_nodes) {
 #if RTX_ASM_NODE_LOAD
         const NodeRec cur = load_node_at(nodes, i);
@@ -656,7 +668,7 @@ template <bool COUNT, bool FAST, bool SPHERES = false, bool ANYHIT = false>
 __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
-                                            LaneRay &r, WaveCounters &wc)
+                                            LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u)
 {
     unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
     // direction classes: six compares voted one by one (direction_is_regular); the hard test runs only when some
@@ -671,8 +683,8 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     if (COUNT) n_active = __popcll(alive);
     // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
     // the choice inside the loop every node paid two more taken branches on the scalar unit)
-    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc);
-    else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc);
+    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
+    else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
     return true;
 }
 
@@ -682,9 +694,9 @@ template <bool COUNT, bool FAST, bool SPHERES = false>
 __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                         const TriRec RTX_CONSTANT *__restrict__ tris,
                                         const ShadeRec *__restrict__ shade, uint32_t n_nodes,
-                                        LaneRay &r, WaveCounters &wc)
+                                        LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u)
 {
-    return closest_hit<COUNT, FAST, SPHERES, true>(nodes, tris, shade, n_nodes, r, wc);
+    return closest_hit<COUNT, FAST, SPHERES, true>(nodes, tris, shade, n_nodes, r, wc, n_global);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -541,6 +541,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                 s.nodes.push_back(a);
                 s.nodes.push_back(b);
             }
+            s.n_global = 0;
             s.n_leaves = static_cast<uint32_t>(s.nodes.size() == 1 ? 1 : 2);
             s.max_leaf_tris = std::max(n_tri_prims, n_prims - n_tri_prims);
             s.depth = s.nodes.size() == 1 ? 1 : 2;
@@ -549,11 +550,61 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             double box_cost = 1.0;
             if (const char *e = std::getenv("RTX_LEAF_MAX")) leaf_max = std::max(1, std::atoi(e));
             if (const char *e = std::getenv("RTX_SAH_BOX_COST")) box_cost = std::atof(e);
+            // "Global" primitives: triangles whose own box is about as large as the scene's (the ground of main()).
+            // Every ray meets such a box, so testing it is wasted work, and as a child of the root it makes the root's
+            // other child — the actual scene — one level deeper for everybody.  They go into the first leaf, which
+            // the walk processes up front without a box test (acceptance without a test is always sound: culling is
+            // a superset), under a root that is never tested either; the tree proper hangs beside it.
+            s.n_global = 0;
+            Box all;
+            all.reset();
+            for (const Prim &p : prims) all.grow(p.lo, p.hi);
+            const double scene_area = all.half_area();
+            if (scene_area > 0 && !std::getenv("RTX_NO_GLOBAL_LEAF")) {
+                auto is_global = [&](const Prim &p) {
+                    Box b;
+                    std::memcpy(b.lo, p.lo, 12);
+                    std::memcpy(b.hi, p.hi, 12);
+                    return p.kind == 0u && b.half_area() >= 0.5 * scene_area;
+                };
+                const size_t n = static_cast<size_t>(std::count_if(prims.begin(), prims.end(), is_global));
+                if (n >= 1 && n <= kMaxGlobalPrims) {
+                    std::stable_partition(prims.begin(), prims.end(), is_global);
+                    s.n_global = static_cast<uint32_t>(n);
+                }
+            }
             TreeBuilder tb(prims, s.nodes, leaf_max, box_cost);
-            tb.build(0, n_prims, 0);
-            s.n_leaves = tb.leaves;
-            s.max_leaf_tris = tb.max_leaf;
-            s.depth = tb.depth;
+            if (s.n_global) {
+                Box g;
+                g.reset();
+                for (uint32_t i = 0; i < s.n_global; ++i) g.grow(prims[i].lo, prims[i].hi);
+                NodeRec leaf;
+                std::memcpy(leaf.bmin, g.lo, 12);
+                std::memcpy(leaf.bmax, g.hi, 12);
+                leaf.info = kLeafFlag | 0u;
+                leaf.link = s.n_global;
+                if (s.n_global < n_prims) {
+                    NodeRec root;
+                    std::memcpy(root.bmin, all.lo, 12);
+                    std::memcpy(root.bmax, all.hi, 12);
+                    root.info = 0;
+                    root.link = 0;
+                    s.nodes.push_back(root);
+                    s.nodes.push_back(leaf);
+                    tb.build(s.n_global, n_prims, 1);
+                    s.nodes[0].link = static_cast<uint32_t>(s.nodes.size());
+                } else {
+                    s.nodes.push_back(leaf);
+                }
+                s.n_leaves = tb.leaves + 1;
+                s.max_leaf_tris = tb.max_leaf;          // of the tree proper; the global leaf holds n_global
+                s.depth = tb.depth + 1;
+            } else {
+                tb.build(0, n_prims, 0);
+                s.n_leaves = tb.leaves;
+                s.max_leaf_tris = tb.max_leaf;
+                s.depth = tb.depth;
+            }
         }
         s.tris.resize(n_prims);
         std::vector<uint32_t> pos_of(n_prims);

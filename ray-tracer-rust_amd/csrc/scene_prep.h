@@ -89,7 +89,9 @@ struct PreparedScene {
     std::vector<float>    light_points;// nb_ray x nb_light_sample x 3
     float gamma_thr[256];
     uint32_t n_leaves = 0, max_leaf_tris = 0, depth = 0;
+    uint32_t n_global = 0;   // > 0: records [0, n_global) are the "global" triangles, stream = root, their leaf, the tree proper
 };
+constexpr uint32_t kMaxGlobalPrims = 8u;
 
 // Returns RTX_OK or a negative RtxError.
 int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);

@@ -73,7 +73,7 @@ class Stats(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n_tris", "n_nodes", "n_leaves", "max_leaf_tris", "depth", "n_light_points",
-                                          "n_ref_nodes", "reserved")] + \
+                                          "n_ref_nodes", "n_global")] + \
                [(n, C.c_uint64) for n in ("node_bytes", "tri_bytes", "shade_bytes", "sample_bytes")]
 
     def asdict(self):

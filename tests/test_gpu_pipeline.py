@@ -136,3 +136,21 @@ def test_every_tile_of_a_4096_square_frame_is_rendered_exactly_once(rtx, orc, sa
     for row in (2000, 2100, 4095):             # across the mesh, across its shadow, the last row
         ref, _ = osc.render_rows(row, 1, mode=orc.MODE_BVH)
         assert np.array_equal(frames[0][row:row + 1], ref), "row %d" % row
+
+
+def test_scenes_whose_triangles_are_all_or_partly_global(rtx, orc, samples_seeded):
+    """Triangles as large as the scene are tested up front, outside the tree (host: n_global): a scene of nothing but
+    such triangles (one-leaf stream), and a soup over a floor that spans it (one global triangle beside the tree)."""
+    kw = dict(AXIS, nb_light_sample=12)
+    W = H = 32
+    walls = np.array([[-9, -9, -5, 9, -9, -5, 0, 9, -5], [-9, -9, -6, 9, -9, -6, 0, 9, -6]], F)
+    tris, rgb = soup(46, 150)
+    floor = np.array([[-40, -7, 10, 40, -7, 10, 0, -7, -60]], F)
+    for name, t, c, want in (("walls", walls, np.array([[1, 0.5, 0.25], [0.2, 0.9, 0.4]], F), 2),
+                             ("soup on a floor", np.concatenate([tris, floor]),
+                              np.concatenate([rgb, np.array([[0.5, 0.5, 0.5]], F)]), 1)):
+        ref, ost = orc.Scene(W, H, t, c, samples_seeded, **kw).render_rows(mode=orc.MODE_BVH)
+        with rtx.Scene(W, H, t, c, samples_seeded, **kw) as s:
+            assert s.info()["n_global"] == want, name
+            img, st = s.render_rows(stats=True)
+        assert st["primary_hits"] == ost["primary_hits"] > 0 and np.array_equal(img, ref), name

@@ -303,3 +303,26 @@ def test_synthetic_mesh_generator(rtx):
     with rtx.Scene(16, 16, tris, rgb, rtx.gen_samples(n_pairs=64), tie_rank=None) as s:
         nodes, order = s.nodes()
         _check_stream(nodes, order, tris, len(tris))
+
+
+def test_global_triangles_sit_in_the_first_leaf(rtx, samples_half):
+    """A triangle whose own box is about as large as the scene's (the ground of main()) is tested by every walk up
+    front: stream = root, the leaf of those triangles (records 0 .. n_global-1), the tree proper."""
+    LEAF = 0x80000000
+    tris, rgb = rtx.default_primitives([model("big_bunny.obj")])
+    with rtx.Scene(32, 32, tris, rgb, samples_half[:64], tie_rank=None) as s:
+        info = s.info()
+        nodes, order = s.nodes()
+        assert info["n_global"] == 1 and int(order[0]) == len(tris) - 1            # the ground is the last primitive
+        assert int(nodes[0, 7]) == 0 and int(nodes[0, 3]) == info["n_nodes"]        # root: inner, skips to the end
+        assert int(nodes[1, 7]) == LEAF | 0 and int(nodes[1, 3]) == 1               # its first child: the global leaf
+        assert not int(nodes[2, 7]) & LEAF                                          # then the root of the tree proper
+        _check_stream(nodes, order, tris, len(tris))
+    mesh = tris[:-1]                                                                # no ground: nothing is global
+    with rtx.Scene(32, 32, mesh, rgb[:-1], samples_half[:64], tie_rank=None) as s:
+        assert s.info()["n_global"] == 0
+    walls = np.array([[-9, -9, -5, 9, -9, -5, 0, 9, -5], [-9, -9, -6, 9, -9, -6, 0, 9, -6]], np.float32)
+    with rtx.Scene(8, 8, walls, np.ones((2, 3), np.float32), samples_half[:64], tie_rank=None) as s:   # all global
+        info = s.info()
+        nodes, order = s.nodes()
+        assert info["n_global"] == 2 and info["n_nodes"] == 1 and int(nodes[0, 3]) == 2
