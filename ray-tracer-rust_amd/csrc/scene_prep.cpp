@@ -408,6 +408,8 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
     if (!d.width || !d.height || !n_prims64 || !d.samples || !d.n_samples || !d.nb_ray) return RTX_ERR_BAD_ARG;
     if ((d.n_tris && (!d.v0v1v2 || !d.rgb)) || (d.n_spheres && (!d.spheres || !d.sphere_rgb))) return RTX_ERR_BAD_ARG;
     if (n_prims64 > kLeafIndexMask || d.accel > RTX_ACCEL_BRUTE || d.reference_tree > RTX_REFTREE_NEVER) return RTX_ERR_BAD_ARG;
+    // the walk addresses records by 32-bit byte offsets (64 B per primitive, 32 B per node, < 2 nodes per primitive)
+    if (n_prims64 >= kMaxPrimitives) return RTX_ERR_UNSUPPORTED;
     if (static_cast<uint64_t>(d.width) * d.height >= (1ull << 31)) return RTX_ERR_BAD_ARG;
     const uint32_t n_prims = static_cast<uint32_t>(n_prims64);
     if (d.kinds) {

@@ -92,6 +92,7 @@ struct PreparedScene {
     uint32_t n_global = 0;   // > 0: records [0, n_global) are the "global" triangles, stream = root, their leaf, the tree proper
 };
 constexpr uint32_t kMaxGlobalPrims = 8u;
+constexpr uint64_t kMaxPrimitives = 1ull << 26;   // 64 B x 2^26 = 4 GiB of records: the limit of a 32-bit byte offset
 
 // Returns RTX_OK or a negative RtxError.
 int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);
