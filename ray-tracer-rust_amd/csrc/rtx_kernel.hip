@@ -890,8 +890,8 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
     if (key != kNone) W.buckets[kOrderList + start[key] + slot] = i;
 }
 
-// Without the primary phase the kernel fits 64 VGPRs (8 wavefronts per SIMD, 4 workgroups per CU) with three
-// loop-invariant dwords in scratch, reloaded once per tile; measured 2.22 ms against 2.28 ms at 6 per SIMD (C3).
+// Without the primary phase the kernel fits the 64 VGPRs of 8 wavefronts per SIMD (4 workgroups per CU): 53 VGPRs, no
+// scratch in the shipped build; when it first went in, 8 per SIMD measured 2.22 ms against 2.28 ms at 6 (C3).
 #ifndef RTX_SHADE_WAVES_PER_SIMD
 #define RTX_SHADE_WAVES_PER_SIMD 8
 #endif
