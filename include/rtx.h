@@ -215,6 +215,23 @@ void rtxh_camera_new(const float eye[3], const float look_at[3], const float up[
 /* import_obj, src/main.rs:114-149: returns the triangle count (>= 0) and a malloc'ed n x 9 array
  * in *v0v1v2 (free with rtxh_free), or a negative RtxError. */
 int  rtxh_import_obj(const char *path, float **v0v1v2);
+/* The same loader with what import_obj leaves out, each part opt-in so that flags = 0 is import_obj
+ * bit for bit (the reference's own assets use none of it):
+ *   RTXH_OBJ_SLASHES    face tokens "v/vt/vn", "v//vn", "v/vt": the vertex index is the part before the first '/'
+ *   RTXH_OBJ_RELATIVE   negative indices count back from the vertices read so far (-1 = the last one)
+ *   RTXH_OBJ_POLYGONS   faces with more than three vertices become a fan (v0,v1,v2), (v0,v2,v3), ...
+ *                       (import_obj silently keeps the first three)
+ *   RTXH_OBJ_MATERIALS  "mtllib f" / "usemtl m": a triangle takes the Kd of the current material, read from the
+ *                       .mtl file beside the OBJ (import_obj gives every mesh triangle Color::new(1,1,1),
+ *                       src/main.rs:146); unknown material or unreadable library: (1,1,1)
+ * With any flag set, tokens are separated by runs of blanks and tabs (import_obj splits on every single space).
+ * *rgb (may be NULL) receives a malloc'ed n x 3 array of colours.  Returns the triangle count or a negative RtxError. */
+#define RTXH_OBJ_SLASHES   1u
+#define RTXH_OBJ_RELATIVE  2u
+#define RTXH_OBJ_POLYGONS  4u
+#define RTXH_OBJ_MATERIALS 8u
+#define RTXH_OBJ_ALL       15u
+int  rtxh_import_obj_ex(const char *path, uint32_t flags, float **v0v1v2, float **rgb);
 void rtxh_free(void *p);
 /* rank of each primitive in the left-to-right leaf order of BoundingVolumeHierarchy::new
  * (bounding_volume_hierarchy.rs:173-226; O(n^2)): out_rank[i] for triangle i. */

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -125,6 +126,137 @@ int rtxh_import_obj(const char *path, float **v0v1v2)
     if (!out) return RTX_ERR_OOM;
     if (n) std::memcpy(out, tris.data(), tris.size() * sizeof(float));
     *v0v1v2 = out;
+    return static_cast<int>(n);
+}
+
+}  // extern "C"
+
+namespace {
+
+std::vector<std::string> split_on_blanks(const std::string &line)
+{
+    std::vector<std::string> tok;
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && (line[i] == ' ' || line[i] == '\t')) ++i;
+        size_t j = i;
+        while (j < line.size() && line[j] != ' ' && line[j] != '\t') ++j;
+        if (j > i) tok.push_back(line.substr(i, j - i));
+        i = j;
+    }
+    return tok;
+}
+
+// "newmtl name" ... "Kd r g b" -> name -> colour; anything else is ignored
+bool read_mtl(const std::string &path, std::vector<std::pair<std::string, std::array<float, 3>>> &out)
+{
+    std::ifstream in(path);
+    if (!in) return false;
+    std::string line, current;
+    bool have = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const std::vector<std::string> tok = split_on_blanks(line);
+        if (tok.empty()) continue;
+        if (tok[0] == "newmtl" && tok.size() >= 2) {
+            current = tok[1];
+            have = true;
+            out.push_back({current, {1.0f, 1.0f, 1.0f}});
+        } else if (tok[0] == "Kd" && tok.size() >= 4 && have) {
+            std::array<float, 3> c;
+            if (parse_f32(tok[1], c[0]) && parse_f32(tok[2], c[1]) && parse_f32(tok[3], c[2])) out.back().second = c;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtxh_import_obj_ex(const char *path, uint32_t flags, float **v0v1v2, float **rgb)
+{
+    if (!path || !v0v1v2 || (flags & ~RTXH_OBJ_ALL)) return RTX_ERR_BAD_ARG;
+    *v0v1v2 = nullptr;
+    if (rgb) *rgb = nullptr;
+    std::vector<float> tris, cols;
+    if (flags == 0u) {   // import_obj itself, every triangle Color::new(1,1,1) (src/main.rs:146)
+        float *t = nullptr;
+        const int n = rtxh_import_obj(path, &t);
+        if (n < 0) return n;
+        *v0v1v2 = t;
+        if (rgb) {
+            float *c = static_cast<float *>(std::malloc(n ? static_cast<size_t>(n) * 3 * sizeof(float) : sizeof(float)));
+            if (!c) { std::free(t); *v0v1v2 = nullptr; return RTX_ERR_OOM; }
+            for (size_t i = 0; i < static_cast<size_t>(n) * 3; ++i) c[i] = 1.0f;
+            *rgb = c;
+        }
+        return n;
+    }
+    std::ifstream in(path);
+    if (!in) return RTX_ERR_IO;
+    const std::string spath(path);
+    const size_t slash = spath.find_last_of("/\\");
+    const std::string dir = slash == std::string::npos ? std::string() : spath.substr(0, slash + 1);
+    std::vector<float> verts;
+    std::vector<std::pair<std::string, std::array<float, 3>>> materials;
+    std::array<float, 3> colour = {1.0f, 1.0f, 1.0f};
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const std::vector<std::string> tok = split_on_blanks(line);
+        if (tok.empty() || tok[0][0] == '#') continue;
+        if (tok[0] == "v") {
+            if (tok.size() < 4) return RTX_ERR_IO;
+            float xyz[3];
+            for (int k = 0; k < 3; ++k)
+                if (!parse_f32(tok[1 + k], xyz[k])) return RTX_ERR_IO;
+            verts.insert(verts.end(), xyz, xyz + 3);
+        } else if (tok[0] == "f") {
+            if (tok.size() < 4) return RTX_ERR_IO;
+            const size_t n_corners = (flags & RTXH_OBJ_POLYGONS) ? tok.size() - 1 : 3;
+            std::vector<size_t> ids(n_corners);
+            for (size_t k = 0; k < n_corners; ++k) {
+                std::string t = tok[1 + k];
+                const size_t sl = t.find('/');
+                if (sl != std::string::npos) {
+                    if (!(flags & RTXH_OBJ_SLASHES)) return RTX_ERR_IO;
+                    t = t.substr(0, sl);
+                }
+                const size_t n_verts = verts.size() / 3;
+                size_t id = 0;
+                if (!t.empty() && t[0] == '-') {
+                    size_t back = 0;
+                    if (!(flags & RTXH_OBJ_RELATIVE) || !parse_index(t.substr(1), back) || back < 1 || back > n_verts)
+                        return RTX_ERR_IO;
+                    id = n_verts - back + 1;
+                } else if (!parse_index(t, id) || id < 1 || id > n_verts) {
+                    return RTX_ERR_IO;
+                }
+                ids[k] = id;
+            }
+            for (size_t k = 2; k < n_corners; ++k) {                 // fan around the first corner
+                for (size_t id : {ids[0], ids[k - 1], ids[k]})
+                    tris.insert(tris.end(), verts.begin() + 3 * (id - 1), verts.begin() + 3 * id);
+                cols.insert(cols.end(), colour.begin(), colour.end());
+            }
+        } else if ((flags & RTXH_OBJ_MATERIALS) && tok[0] == "mtllib" && tok.size() >= 2) {
+            (void)read_mtl(dir + tok[1], materials);
+        } else if ((flags & RTXH_OBJ_MATERIALS) && tok[0] == "usemtl" && tok.size() >= 2) {
+            colour = {1.0f, 1.0f, 1.0f};
+            for (const auto &m : materials)
+                if (m.first == tok[1]) colour = m.second;           // the last definition wins
+        }
+    }
+    const size_t n = tris.size() / 9;
+    if (n > 0x3FFFFFFFu) return RTX_ERR_UNSUPPORTED;
+    float *t = static_cast<float *>(std::malloc(n ? tris.size() * sizeof(float) : sizeof(float)));
+    float *c = rgb ? static_cast<float *>(std::malloc(n ? cols.size() * sizeof(float) : sizeof(float))) : nullptr;
+    if (!t || (rgb && !c)) { std::free(t); std::free(c); return RTX_ERR_OOM; }
+    if (n) std::memcpy(t, tris.data(), tris.size() * sizeof(float));
+    if (n && c) std::memcpy(c, cols.data(), cols.size() * sizeof(float));
+    *v0v1v2 = t;
+    if (rgb) *rgb = c;
     return static_cast<int>(n);
 }
 

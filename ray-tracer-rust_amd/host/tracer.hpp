@@ -175,6 +175,24 @@ inline std::vector<primitives::Primitive> import_obj(const std::string &path, in
     return out;
 }
 
+// The loader with what import_obj leaves out (rtxh_import_obj_ex: "v/vt/vn" tokens, relative indices, polygons as
+// fans, Kd colours of mtllib/usemtl), each part opt-in: flags = 0 is import_obj.
+inline std::vector<primitives::Primitive> import_obj_ex(const std::string &path, uint32_t flags, int *err = nullptr)
+{
+    std::vector<primitives::Primitive> out;
+    float *tris = nullptr, *rgb = nullptr;
+    const int n = rtxh_import_obj_ex(path.c_str(), flags, &tris, &rgb);
+    if (err) *err = n < 0 ? n : RTX_OK;
+    for (int i = 0; i < n; ++i) {
+        const float *t = tris + 9 * static_cast<size_t>(i), *c = rgb + 3 * static_cast<size_t>(i);
+        out.emplace_back(primitives::Triangle::create({t[0], t[1], t[2]}, {t[3], t[4], t[5]}, {t[6], t[7], t[8]},
+                                                      utils::Color::create(c[0], c[1], c[2])));
+    }
+    rtxh_free(tris);
+    rtxh_free(rgb);
+    return out;
+}
+
 // gen_random_spheres — src/main.rs:42-67: one sphere, radius in [400, 500), at (0, 0, -1000), random colour.
 // gen_random_triangles — src/main.rs:69-99: ten triangles, x and y in [-500, 500), z in [-100, -50), random colour.
 // The reference draws from thread_rng; the stand-in is the library's seeded generator, values taken in the

@@ -105,6 +105,7 @@ _SIGS = {
     "rtx_scene_ref_nodes": (C.c_int, [C.c_void_p, u32p]),
     "rtxh_camera_new": (None, [f32p] * 6),
     "rtxh_import_obj": (C.c_int, [C.c_char_p, C.POINTER(f32p)]),
+    "rtxh_import_obj_ex": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(f32p), C.POINTER(f32p)]),
     "rtxh_free": (None, [C.c_void_p]),
     "rtxh_ref_leaf_rank": (C.c_int, [C.c_uint32, f32p, u32p]),
     "rtxh_gen_samples": (None, [C.c_uint64, C.c_uint32, f32p]),
@@ -164,6 +165,23 @@ def import_obj(path):
     arr = np.ctypeslib.as_array(p, shape=(max(n, 1), 9))[:n].copy() if n else np.zeros((0, 9), np.float32)
     _lib.rtxh_free(p)
     return arr
+
+
+OBJ_SLASHES, OBJ_RELATIVE, OBJ_POLYGONS, OBJ_MATERIALS, OBJ_ALL = 1, 2, 4, 8, 15
+
+
+def import_obj_ex(path, flags=OBJ_ALL):
+    """The loader with slashes, relative indices, polygons and material colours (each opt-in; flags = 0 is
+    import_obj with every triangle white) -> (float32 [n, 9], float32 [n, 3])."""
+    t, c = f32p(), f32p()
+    n = _lib.rtxh_import_obj_ex(os.fsencode(path), flags, C.byref(t), C.byref(c))
+    if n < 0:
+        raise RtxError(n, "rtxh_import_obj_ex(%s)" % path)
+    tris = np.ctypeslib.as_array(t, shape=(max(n, 1), 9))[:n].copy() if n else np.zeros((0, 9), np.float32)
+    rgb = np.ctypeslib.as_array(c, shape=(max(n, 1), 3))[:n].copy() if n else np.zeros((0, 3), np.float32)
+    _lib.rtxh_free(t)
+    _lib.rtxh_free(c)
+    return tris, rgb
 
 
 def ref_leaf_rank(tris):
