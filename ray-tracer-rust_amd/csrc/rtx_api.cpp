@@ -123,7 +123,8 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     if (st.uploaded) return RTX_OK;
     const rtx::PreparedScene &p = scene->prep;
     int rc;
-    if ((rc = upload_vec(&st.nodes, rtx::nodes_in_device_order(p.nodes), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
+    const float inflate = RTX_CULL_INFLATED ? p.cull_delta : 0.0f;
+    if ((rc = upload_vec(&st.nodes, rtx::nodes_in_device_order(p.nodes, inflate), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
     if (!p.ref_nodes.empty() &&
         (rc = upload_vec(&st.ref_nodes, rtx::nodes_in_device_order(p.ref_nodes), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.tris, p.tris)) != RTX_OK) return rc;

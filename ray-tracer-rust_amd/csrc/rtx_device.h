@@ -7,6 +7,12 @@
 
 #include "scene_prep.h"
 
+// The library's node stream is uploaded with its planes moved outwards by PreparedScene::cull_delta and the
+// multiply-based box test then needs no widening of its own (rtx_traverse.hpp: box_mask); 0 = exact boxes + widening.
+#ifndef RTX_CULL_INFLATED
+#define RTX_CULL_INFLATED 1
+#endif
+
 namespace rtx {
 
 // Everything the kernel reads, resident in HBM for the life of the upload.

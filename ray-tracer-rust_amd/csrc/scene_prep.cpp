@@ -496,6 +496,14 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             p.kind = sphere ? 1u : 0u;
         }
 
+        {   // PreparedScene::cull_delta
+            float magnitude = 0.0f;
+            for (float b : boxes) magnitude = std::fmax(magnitude, std::fabs(b));
+            for (int k = 0; k < 3; ++k) magnitude = std::fmax(magnitude, std::fabs(d.eye[k]));
+            s.cull_delta = magnitude * 0x1p-19f + 0x1p-100f;
+            if (!std::isfinite(s.cull_delta)) return RTX_ERR_UNSUPPORTED;
+        }
+
         // the reference's own tree (see ref_tree_build): ranks for exact ties, stream for hard directions
         std::vector<uint32_t> ref_rank;
         s.ref_nodes.clear();

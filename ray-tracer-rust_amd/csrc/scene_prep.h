@@ -37,11 +37,14 @@ struct NodeDev {
     uint32_t link, info;
 };
 static_assert(sizeof(NodeDev) == sizeof(NodeRec), "NodeDev is a permutation of NodeRec");
-inline std::vector<NodeDev> nodes_in_device_order(const std::vector<NodeRec> &v)
+// inflate > 0: every plane is moved outwards by that much (PreparedScene::cull_delta) — the library's own stream only,
+// whose boxes cull and nothing else; the reference-tree stream must stay exact.
+inline std::vector<NodeDev> nodes_in_device_order(const std::vector<NodeRec> &v, float inflate = 0.0f)
 {
     std::vector<NodeDev> out(v.size());
     for (size_t i = 0; i < v.size(); ++i)
-        out[i] = NodeDev{v[i].bmin[0], v[i].bmin[1], v[i].bmax[0], v[i].bmax[1], v[i].bmin[2], v[i].bmax[2], v[i].link, v[i].info};
+        out[i] = NodeDev{v[i].bmin[0] - inflate, v[i].bmin[1] - inflate, v[i].bmax[0] + inflate, v[i].bmax[1] + inflate,
+                         v[i].bmin[2] - inflate, v[i].bmax[2] + inflate, v[i].link, v[i].info};
     return out;
 }
 constexpr uint32_t kLeafFlag = 0x80000000u;
@@ -89,6 +92,10 @@ struct PreparedScene {
     std::vector<float>    light_points;// nb_ray x nb_light_sample x 3
     float gamma_thr[256];
     uint32_t n_leaves = 0, max_leaf_tris = 0, depth = 0;
+    // Outward shift of the culling planes on the device, 2^-19 x the largest coordinate magnitude of the scene and the
+    // eye: it absorbs the error of the multiply-based plane distances (at most 11.01 * 2^-24 of that magnitude in
+    // position units, rtx_traverse.hpp), so that the box test needs no per-test widening.
+    float cull_delta = 0.0f;
     uint32_t n_global = 0;   // > 0: records [0, n_global) are the "global" triangles, stream = root, their leaf, the tree proper
 };
 constexpr uint32_t kMaxGlobalPrims = 8u;
