@@ -739,15 +739,22 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
     return k < kCostBuckets ? k : kCostBuckets - 1u;
 }
 
+// independent wavefronts (tiles) per workgroup of probe_kernel: 1, 4 and 8 measured the same (m_ab_probewaves.log)
+#ifndef RTX_PROBE_WAVES
+#define RTX_PROBE_WAVES 1
+#endif
+
 template <bool COUNT, bool FAST, bool SPHERES>
-__global__ void __launch_bounds__(64) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
+__global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
                                                    uint32_t r, StreamWorkspace W, uint8_t *__restrict__ out,
                                                    uint32_t *__restrict__ queue, unsigned long long *__restrict__ counters)
 {
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t tile_id = blockIdx.x;
+    // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no LDS, no barrier)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile_id = blockIdx.x * RTX_PROBE_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (tile_id >= n_tiles) return;
     uint32_t px, py, ly;
     const bool in_frame = tile_pixel(S, ts, tile_id % tiles_x, tile_id / tiles_x, lane, px, py, ly);
     WaveCounters wc;
@@ -1070,7 +1077,8 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(W.buckets, 0, 3u * kCostBuckets * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>), dim3(n_tiles), dim3(64), 0, stream, S, ts, tiles_x, n_tiles,
+        hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>), dim3((n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
+                           dim3(64 * RTX_PROBE_WAVES), 0, stream, S, ts, tiles_x, n_tiles,
                            r, W, d_out, d_redo, d_counters);
         hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
         hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
