@@ -34,6 +34,7 @@
 //
 // The gamma curve is not evaluated on the device: scene_prep locates the 255 byte steps of
 // (x.powf(1/2.2)*255) as u8 with the host libm and the kernels count thresholds <= x.
+#include <cstdlib>
 #include "rtx_traverse.hpp"
 
 namespace rtx {
@@ -744,6 +745,8 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
 #define RTX_PROBE_WAVES 1
 #endif
 
+// (Requesting the next stream record before the current one is tested — the next one visited unless an inner node
+//  fails — did not shorten this kernel: 0.1446 against 0.1416 ms for the scheduling pass of C3, same box, interleaved.)
 template <bool COUNT, bool FAST, bool SPHERES>
 __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
                                                    uint32_t r, StreamWorkspace W, uint8_t *__restrict__ out,
@@ -838,14 +841,38 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 }
 
 // Counting sort of the scheduled tiles by cost class, costliest first.  Workspace words (W.buckets):
-//   [0] number of tiles in the order   [kOrderHist + k] tiles of class k (count_classes_kernel)
-//   [kOrderCursor + k] tiles of class k already placed   [kOrderList + i] the i-th tile
+//   [0] number of jobs in the order   [kOrderHist + k] tiles of class k (count_classes_kernel)
+//   [kOrderCursor + k] tiles of class k already placed   [kOrderList + i] the i-th job
 // One workgroup per 1024 tiles: a class's position range starts where the costlier classes end (prefix over the
 // histogram); inside it each workgroup reserves a block with one atomic per class it holds, and its tiles take
 // consecutive slots.  Equal classes within a wavefront are counted by one lane — neighbouring tiles mostly share a
 // class — so the LDS atomics stay few.  (A single workgroup walking all tiles took 48 us of a 1.9 ms frame; one global
 // atomic per tile from probe_kernel — thousands on the few addresses of the common classes — added 90 us to it.)
+//
+// A job is a tile or a PART of one.  The pixels of a tile accumulate independently of each other (main.rs:180-240 is
+// per pixel), so a tile's hit pixels can be dealt to several workgroups — hit records [p n / P, (p + 1) n / P) to
+// part p — without touching any pixel's own order of additions.  That matters when a launch has few tiles per
+// workgroup (one GPU's share of an 8-GPU frame): the costliest tile alone, 100 chunks walked by 8 wavefronts, then
+// outlasts everything else (tools/share_timing.py: 0.48 ms of shading for an eighth of a 1.2 ms frame).  Every class
+// whose tiles cost more than kSplitShare of a workgroup's fair share of the launch's estimated cost is cut into the
+// power of two of parts that brings it below, at most kMaxTileParts.
 constexpr uint32_t kOrderHist = kCostBuckets, kOrderCursor = 2u * kCostBuckets, kOrderList = 3u * kCostBuckets;
+#ifndef RTX_TILE_PARTS_MAX
+#define RTX_TILE_PARTS_MAX 16
+#endif
+constexpr uint32_t kMaxTileParts = RTX_TILE_PARTS_MAX;               // 1 = never split
+static_assert(kMaxTileParts >= 1u && kMaxTileParts <= 16u && (kMaxTileParts & (kMaxTileParts - 1u)) == 0u, "parts: a power of two <= 16");
+constexpr uint32_t kNotMine = 0xFFFFFFFEu;                          // shade_tiles_kernel: a pixel of another part of the tile
+// job = tile | part << 25 | log2(parts) << 29  (log2(parts) <= 4, so no job equals kNone)
+constexpr uint32_t kJobTileBits = 25u, kJobTileMask = (1u << kJobTileBits) - 1u, kJobPartsShift = 29u;
+
+// lower end of cost class k (cost_class above): k = 2 floor(log2 c) + (second bit of c) + 1
+__device__ __forceinline__ float class_cost(uint32_t k)
+{
+    if (k == 0u) return 0.0f;
+    const uint32_t lz = (k - 1u) >> 1, half = (k - 1u) & 1u;
+    return lz ? (float)(2u + half) * (float)(1u << (lz - 1u)) : 1.0f;
+}
 
 __global__ void __launch_bounds__(1024) count_classes_kernel(uint32_t n_tiles, StreamWorkspace W)
 {
@@ -866,11 +893,15 @@ __global__ void __launch_bounds__(1024) count_classes_kernel(uint32_t n_tiles, S
     if (tid < kCostBuckets && count[tid] != 0u) atomicAdd(&W.buckets[kOrderHist + tid], count[tid]);
 }
 
-__global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, StreamWorkspace W)
+__global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, StreamWorkspace W, uint32_t shade_grid, float split_share)
 {
-    __shared__ uint32_t count[kCostBuckets], start[kCostBuckets];
+    __shared__ uint32_t count[kCostBuckets], start[kCostBuckets], parts_log[kCostBuckets], jobs[kCostBuckets];
+    __shared__ float weight[kCostBuckets];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    if (tid < kCostBuckets) count[tid] = 0u;
+    if (tid < kCostBuckets) {
+        count[tid] = 0u;
+        weight[tid] = (float)W.buckets[kOrderHist + tid] * class_cost(tid);
+    }
     __syncthreads();
     const uint32_t i = blockIdx.x * 1024u + tid;
     const uint32_t key = i < n_tiles ? W.tiles[i].first : kNone;
@@ -885,16 +916,36 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
         if (key == k0) slot = off + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
         todo &= ~same;
     }
-    __syncthreads();
     if (tid < kCostBuckets) {
-        uint32_t before = 0u;                 // tiles of costlier classes
-        for (uint32_t k = tid + 1u; k < kCostBuckets; ++k) before += W.buckets[kOrderHist + k];
-        const uint32_t mine = count[tid];
-        start[tid] = before + (mine ? atomicAdd(&W.buckets[kOrderCursor + tid], mine) : 0u);
-        if (blockIdx.x == 0 && tid == 0) W.buckets[0] = before + W.buckets[kOrderHist];
+        // parts per tile of this class: the same numbers in every workgroup (histogram and arguments only)
+        float total = 0.0f;
+        uint32_t scheduled = 0u;
+        for (uint32_t k = 0; k < kCostBuckets; ++k) { total += weight[k]; scheduled += W.buckets[kOrderHist + k]; }
+        // With few tiles per workgroup the makespan is quantised by whole jobs (2 or 3 of them): finer parts then pay
+        // for their fixed cost, which they do not when every workgroup has many jobs to even things out
+        // (tools/share_timing.py: a quarter of the share costs a full C3 frame 3 %, and gains an eighth of it 10 %).
+        const float per_wg = (float)scheduled / (float)shade_grid;
+        const float scale = per_wg >= 16.0f ? 1.0f : (per_wg <= 4.0f ? 0.25f : per_wg * (1.0f / 16.0f));
+        const float limit = split_share * scale * total / (float)shade_grid;
+        uint32_t lg = 0u;
+        while ((1u << lg) < kMaxTileParts && class_cost(tid) > limit * (float)(1u << lg)) ++lg;
+        parts_log[tid] = lg;
+        jobs[tid] = W.buckets[kOrderHist + tid] << lg;
     }
     __syncthreads();
-    if (key != kNone) W.buckets[kOrderList + start[key] + slot] = i;
+    if (tid < kCostBuckets) {
+        uint32_t before = 0u;                 // jobs of costlier classes
+        for (uint32_t k = tid + 1u; k < kCostBuckets; ++k) before += jobs[k];
+        const uint32_t mine = count[tid];
+        start[tid] = before + ((mine ? atomicAdd(&W.buckets[kOrderCursor + tid], mine) : 0u) << parts_log[tid]);
+        if (blockIdx.x == 0 && tid == 0) W.buckets[0] = before + jobs[0];
+    }
+    __syncthreads();
+    if (key != kNone) {
+        const uint32_t lg = parts_log[key];
+        uint32_t *dst = W.buckets + kOrderList + start[key] + (slot << lg);
+        for (uint32_t p = 0; p < (1u << lg); ++p) dst[p] = i | (p << kJobTileBits) | (lg << kJobPartsShift);
+    }
 }
 
 // Without the primary phase the kernel fits the 64 VGPRs of 8 wavefronts per SIMD (4 workgroups per CU): 53 VGPRs, no
@@ -927,34 +978,42 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 
     for (;;) {
         if (threadIdx.x == 0) {
-            // q-th tile, costliest class first
+            // q-th job, costliest class first
             const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
             l_ctl[3] = q < W.buckets[0] ? W.buckets[3u * kCostBuckets + q] : kNone;
             l_ctl[1] = 0u;
         }
         __syncthreads();
-        const uint32_t tile_id = __builtin_amdgcn_readfirstlane(l_ctl[3]);
-        if (tile_id == kNone) break;
+        const uint32_t job = __builtin_amdgcn_readfirstlane(l_ctl[3]);
+        if (job == kNone) break;
+        // part `part` of 2^parts_log of the tile: its hit records [h0, h0 + n_hit), the pixels they belong to, and (part 0)
+        // the tile's pixels without a hit
+        const uint32_t tile_id = job & kJobTileMask, part = (job >> kJobTileBits) & 15u, parts_log = job >> kJobPartsShift;
         const uint32_t tile_x = tile_id % tiles_x, tile_y = tile_id / tiles_x;
         const TileDesc td = W.tiles[tile_id];
-        const uint32_t n_hit = __builtin_amdgcn_readfirstlane(td.n_hit);
+        const uint32_t n_all = __builtin_amdgcn_readfirstlane(td.n_hit);
+        const uint32_t h0 = (part * n_all) >> parts_log;
+        const uint32_t n_hit = (((part + 1u) * n_all) >> parts_log) - h0;
         const uint32_t tflags = __builtin_amdgcn_readfirstlane(td.flags);
         const bool sample_major = (tflags & 1u) != 0u;
         const bool skip = (tflags & 2u) != 0u;      // already queued for the reference re-render
         if (!skip) {
-            const float *src = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u);
+            const float *src = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u + h0);
             for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = src[k];
             if (wave == 0) {
                 const size_t pix = (size_t)tile_id * 64u + lane;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                               // main.rs:182
                 if (r != 0u) { a0 = W.acc[3u * pix]; a1 = W.acc[3u * pix + 1u]; a2 = W.acc[3u * pix + 2u]; }
                 l_pix[4u * lane] = a0; l_pix[4u * lane + 1u] = a1; l_pix[4u * lane + 2u] = a2;
-                reinterpret_cast<uint32_t *>(l_pix)[4u * lane + 3u] = W.pix_slot[pix];
+                // the pixel's hit record within this part; kNone: no hit and the pixel is this part's; kNotMine: another part's
+                const uint32_t g = W.pix_slot[pix];
+                reinterpret_cast<uint32_t *>(l_pix)[4u * lane + 3u] =
+                    g == kNone ? (part == 0u ? kNone : kNotMine) : (g - h0 < n_hit ? g - h0 : kNotMine);
             }
             __syncthreads();
             if (wave == 0) {   // grey tile (every BASELINE scene): the three channel sums are the same f32 sequence
                 const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
-                const bool hit = slot != kNone;
+                const bool hit = slot < 64u;
                 const float *h = l_hit + kHitStride * (hit ? slot : 0u);
                 const float cr = h[6], cg = h[7], cb = h[8];
                 const float a0 = l_pix[4u * lane], a1 = l_pix[4u * lane + 1u], a2 = l_pix[4u * lane + 2u];
@@ -992,7 +1051,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // phase 3: ordered accumulation, one work-item per pixel (wave 0)
                     if (wave == 0) {
                         const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
-                        const bool hit = slot != kNone;
+                        const bool hit = slot < 64u;
                         float acc_r = l_pix[4u * lane], acc_g = l_pix[4u * lane + 1u], acc_b = l_pix[4u * lane + 2u];
                         const float *h = l_hit + kHitStride * (hit ? slot : 0u);
                         const float cr = h[6], cg = h[7], cb = h[8];
@@ -1022,10 +1081,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 }
             }
             if (wave == 0) {
+                const bool mine = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u] != kNotMine;
                 if (l_ctl[1] != 0u) {   // a hard shadow direction: reference_tiles_kernel redoes the tile and counts its hits
-                    if (lane == 0) {
+                    // (whatever the tile's other parts store is overwritten by it; the first part to get here queues the tile)
+                    if (lane == 0 && !(atomicOr(&W.tiles[tile_id].flags, 2u) & 2u)) {
                         queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_id;
-                        W.tiles[tile_id].flags = tflags | 2u;
                         if (COUNT && counters) {
                             atomicAdd(&counters[5], 1ull);
                             atomicAdd(&counters[0], 0ull - (unsigned long long)td.pad);
@@ -1033,11 +1093,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     }
                 } else if (r + 1u < S.nb_ray) {
                     const size_t pix = (size_t)tile_id * 64u + lane;
-                    W.acc[3u * pix] = l_pix[4u * lane]; W.acc[3u * pix + 1u] = l_pix[4u * lane + 1u];
-                    W.acc[3u * pix + 2u] = l_pix[4u * lane + 2u];
+                    if (mine) {
+                        W.acc[3u * pix] = l_pix[4u * lane]; W.acc[3u * pix + 1u] = l_pix[4u * lane + 1u];
+                        W.acc[3u * pix + 2u] = l_pix[4u * lane + 2u];
+                    }
                 } else {
                     uint32_t px, py, ly;
-                    if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly))
+                    if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly) && mine)
                         store_pixel(S, out, px, ly, l_pix[4u * lane], l_pix[4u * lane + 1u], l_pix[4u * lane + 2u]);
                 }
             }
@@ -1048,6 +1110,18 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 }
 
 namespace {
+
+// kSplitShare: a tile whose estimated cost is above this fraction of a workgroup's fair share of the launch is split
+// (RTX_SPLIT_SHARE overrides it, read once: tools/share_timing.py sweeps it)
+float split_share()
+{
+    static const float v = [] {
+        const char *e = getenv("RTX_SPLIT_SHARE");
+        const float x = e ? strtof(e, nullptr) : 0.0f;
+        return x > 0.0f ? x : 0.5f;
+    }();
+    return v;
+}
 
 template <bool COUNT, bool FAST, bool SPHERES>
 hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
@@ -1072,7 +1146,9 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
         cached_dev = dev;
         cached_lds = lds_bytes;
     }
-    const uint32_t grid = n_tiles < static_cast<uint32_t>(cached_blocks) ? n_tiles : static_cast<uint32_t>(cached_blocks);
+    if (n_tiles > kJobTileMask) return hipErrorInvalidValue;
+    const uint64_t most_jobs = (uint64_t)n_tiles * kMaxTileParts;
+    const uint32_t grid = most_jobs < static_cast<uint64_t>(cached_blocks) ? (uint32_t)most_jobs : static_cast<uint32_t>(cached_blocks);
     if ((e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream)) != hipSuccess) return e;
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
@@ -1081,7 +1157,7 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
                            dim3(64 * RTX_PROBE_WAVES), 0, stream, S, ts, tiles_x, n_tiles,
                            r, W, d_out, d_redo, d_counters);
         hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
-        hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
+        hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W, grid, split_share());
         if (ev && r == 0u && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;   // end of the scheduling pass
         hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
                            batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
@@ -1211,7 +1287,7 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.results = streamed ? pixels * (S.nb_light ? S.nb_light : 1u) * sizeof(float) : 0u;
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);
-    b.buckets = probe ? (3u * kCostBuckets + tiles) * sizeof(uint32_t) : 0u;
+    b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts) * sizeof(uint32_t) : 0u;
     return b;
 }
 
