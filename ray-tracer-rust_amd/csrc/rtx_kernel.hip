@@ -747,6 +747,12 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
 
 // (Requesting the next stream record before the current one is tested — the next one visited unless an inner node
 //  fails — did not shorten this kernel: 0.1446 against 0.1416 ms for the scheduling pass of C3, same box, interleaved.)
+// primary walks of at least this many records are their tile's cost estimate themselves (0: always probe)
+#ifndef RTX_PROBE_SKIP_VISITS
+#define RTX_PROBE_SKIP_VISITS 64
+#endif
+constexpr uint32_t kProbeSkipVisits = RTX_PROBE_SKIP_VISITS;
+
 template <bool COUNT, bool FAST, bool SPHERES>
 __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
                                                    uint32_t r, StreamWorkspace W, uint8_t *__restrict__ out,
@@ -764,7 +770,8 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     float dx, dy, dz;
     primary_ray(S, in_frame, px, py, r, dx, dy, dz);
     LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
-    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
+    // (counted in every build: the walk's length is the cost estimate of a tile that looks into the mesh, below)
+    const bool ok = closest_hit<COUNT || kProbeSkipVisits != 0u, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
     const bool hit = ok && in_frame && pr.best_idx != kNone;
     const unsigned long long hit_mask = ballot(hit);
     const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
@@ -802,7 +809,14 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;
     // cost probe: the walk of light sample 0 for the tile's hit pixels (its result is not used, only its length)
     unsigned long long cost = 0;
-    if (n_hit != 0u && S.nb_light != 0u && !(flags & 2u)) {
+    const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
+    const unsigned long long primary_walk = wc.node_visits + wc.tri_visits;
+    if (kProbeSkipVisits != 0u && primary_walk >= kProbeSkipVisits && n_hit != 0u && !(flags & 2u)) {
+        // A long primary walk: the tile looks into the mesh, and the shadow rays of what it sees start inside the
+        // mesh's boxes — their walks are long too.  The primary walk's own length stands in for the probing walk,
+        // which for these tiles would be the second half of the scheduling pass's critical path.
+        cost = (primary_walk + 1ull) * n_chunks;
+    } else if (n_hit != 0u && S.nb_light != 0u && !(flags & 2u)) {
         const float *lp = S.light_points + 3u * (r * S.nb_light);
         const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;
         const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -810,7 +824,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         sr.limit = dist_light;
         WaveCounters probe;
         (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
-        const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
         cost = (probe.node_visits + probe.tri_visits + 1ull) * n_chunks;
     }
     // A tile without a hit is finished here (main.rs:235: the sums stay as they are), a queued tile belongs to the
