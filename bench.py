@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default="")
+    # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo for the barrier and the reductions
+    # (RCCL refuses two ranks on one device).  Not a measurement: the ranks share the device.
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--ranks-share-device-0", action="store_true")
     return ap.parse_args()
 
 
@@ -102,8 +106,10 @@ def cpu_baseline(wl, samples_np, seconds, threads):
     }
 
 
-def reduce_counters(counters, world):
+def reduce_counters(counters, world, via_host=False):
     """Sum the per-rank kernel counters (each rank counted only its own row tiles)."""
+    if via_host:
+        counters = counters.cpu()
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
@@ -130,12 +136,18 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.ranks_share_device_0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    via_host = args.backend == "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if via_host:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     rtx = importlib.import_module("ray-tracer-rust_amd")
     wl = WORKLOADS[args.workload]
@@ -170,7 +182,7 @@ def main():
     # one counted launch (outside the timed region) gives the frame's ray / test counts
     step(count=True)
     torch.cuda.synchronize(dev)
-    c = reduce_counters(counters, world)
+    c = reduce_counters(counters, world, via_host)
     primary_hits, box_tests, tri_tests, node_visits, tri_visits = c[0], c[1], c[2], c[3], c[4]
     sched_node_visits, sched_tri_visits = c[6], c[7]       # the scheduling pass's (primary rays') share of the fetches
     primary_rays = W * H * rtx.NB_RAY
@@ -194,7 +206,7 @@ def main():
     sched_ms = float(sched_t.mean()) if len(sched_t) else 0.0
     shade_ms = float(shade_t.mean()) if len(shade_t) else kernel_ms
     elapsed, kernel_s, sched_s, shade_s = reduce_times(
-        (elapsed, kernel_ms / 1e3, sched_ms / 1e3, shade_ms / 1e3), world, dev)
+        (elapsed, kernel_ms / 1e3, sched_ms / 1e3, shade_ms / 1e3), world, torch.device("cpu") if via_host else dev)
     ms_per_step = elapsed / args.steps * 1e3
 
     if args.save_png and world == 1:
@@ -236,7 +248,8 @@ def main():
             "data": "%s + seeded sample table (splitmix64 seed %d); no dataset download" % (asset, rtx.DEFAULT_SEED),
             "config": {"workload": wl["desc"] + ", 1 spp, 100 light samples, default scene of src/main.rs:327-358",
                        "width": W, "height": H, "n_tris": info["n_tris"], "tile_rows": tile_rows,
-                       "partition": "row tiles, tile t -> rank t %% %d, no collective" % world,
+                       "partition": "row tiles, tile t -> rank t %% %d, no collective" % world +
+                                    (" (REHEARSAL: all ranks on one device)" if args.ranks_share_device_0 and world > 1 else ""),
                        "accel": "sah-bvh leaf<=%d, %d nodes" % (info["max_leaf_tris"], info["n_nodes"])},
             "frame_ms": round(ms_per_step, 4),
             "rays_per_frame": r_total, "primary_hits": primary_hits,
