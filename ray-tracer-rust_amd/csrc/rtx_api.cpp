@@ -35,7 +35,7 @@ thread_local int g_last_hip_error = 0;
 struct DeviceState {
     std::mutex mu;
     bool uploaded = false;
-    void *nodes = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr;
+    void *nodes = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_out = nullptr;
@@ -131,6 +131,7 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     if ((rc = upload_vec(&st.shade, p.shade)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.samples, p.samples)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.lights, p.light_points)) != RTX_OK) return rc;
+    if (!p.global_planes.empty() && (rc = upload_vec(&st.planes, p.global_planes)) != RTX_OK) return rc;
     RTX_HIP(hipMalloc(&st.thr, sizeof(p.gamma_thr)));
     RTX_HIP(hipMemcpy(st.thr, p.gamma_thr, sizeof(p.gamma_thr), hipMemcpyHostToDevice));
     RTX_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_counters), rtx::kNumCounters * sizeof(unsigned long long)));
@@ -154,6 +155,7 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     S.shade = static_cast<const rtx::ShadeRec *>(st.shade);
     S.samples = static_cast<const float2 *>(st.samples);
     S.light_points = static_cast<const float *>(st.lights);
+    S.planes = static_cast<const rtx::TriRec *>(st.planes);
     S.gamma_thr = static_cast<const float *>(st.thr);
     S.n_nodes = static_cast<uint32_t>(p.nodes.size());
     S.n_samples = p.n_samples;
@@ -332,7 +334,7 @@ void rtx_scene_destroy(RtxScene *scene)
         DeviceGuard g(kv.first);
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
-        void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.d_out, st.d_counters, st.d_redo,
+        void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.d_out, st.d_counters, st.d_redo,
                         st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr, st.ws.buckets};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);

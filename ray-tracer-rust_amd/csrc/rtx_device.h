@@ -22,6 +22,7 @@ struct DeviceScene {
     const NodeRec  *ref_nodes;     // (n_ref_nodes + 1) x 32 B: the reference's own tree, or NULL
     const TriRec   *tris;          // n_tris x 64 B, leaf order
     const ShadeRec *shade;         // n_tris x 32 B, caller order
+    const TriRec   *planes;        // n_global x 64 B: plane data of the global triangles (PreparedScene::global_planes), or NULL
     const float2   *samples;       // n_samples x (s.0, s.1)
     const float    *light_points;  // nb_ray x nb_light x 3
     const float    *gamma_thr;     // 256

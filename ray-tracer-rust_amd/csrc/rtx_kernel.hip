@@ -963,6 +963,9 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 
 // Without the primary phase the kernel fits the 64 VGPRs of 8 wavefronts per SIMD (4 workgroups per CU): 53 VGPRs, no
 // scratch in the shipped build; when it first went in, 8 per SIMD measured 2.22 ms against 2.28 ms at 6 (C3).
+#ifndef RTX_PLANE_SHORTCUT
+#define RTX_PLANE_SHORTCUT 1
+#endif
 #ifndef RTX_SHADE_WAVES_PER_SIMD
 #define RTX_SHADE_WAVES_PER_SIMD 8
 #endif
@@ -983,6 +986,16 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
+    // the first global triangle's plane, fetched once (rtx_traverse.hpp: plane_rules_out)
+    const TriRec RTX_CONSTANT *planes = (const TriRec RTX_CONSTANT *)S.planes;
+    const bool have_plane = RTX_PLANE_SHORTCUT && planes != nullptr;
+    TriRec plane0 = {};
+    if (have_plane) {
+        plane0.v0[0] = planes->v0[0]; plane0.v0[1] = planes->v0[1]; plane0.v0[2] = planes->v0[2];
+        plane0.e1[0] = planes->e1[0]; plane0.e1[1] = planes->e1[1]; plane0.e1[2] = planes->e1[2];
+        plane0.e2[0] = planes->e2[0]; plane0.e2[1] = planes->e2[1]; plane0.e2[2] = planes->e2[2];
+        plane0.bmin[0] = planes->bmin[0];
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveCounters wc;
@@ -1055,7 +1068,9 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
                         const uint32_t rem = (c0 + lane) - __umul24(quo, div);
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
-                        const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global);   // main.rs:204
+                        const bool no_ground = have_plane &&
+                            (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
+                        const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
                         if (!ok && lane == 0) l_ctl[1] = 1u;
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
                         else shadow_result(l_hit, l_res, res_stride, sr);

@@ -646,13 +646,45 @@ __device__ __forceinline__ NodeRec load_node_at(const NodeRec RTX_CONSTANT *base
     return r;
 }
 
+// A global triangle (the ground) is tested by EVERY walk, and nearly every ray either starts on it or moves away
+// from it: Triangle::intersect then returns a t < 1.0 (bvh.rs:64 drops it) — 45 vector instructions to learn nothing.
+// That outcome can be certified from the plane alone.  With N = e1 x e2 (exact), tv = fl(o - v0) as the reference
+// computes it, the reference's numerator and denominator are roundings of  tv.N  and  -d.N :
+//     n~ = fl(e2 . fl(tv x e1)),  |n~ - tv.N| <= 5.1 u (|tv| . W)         (five roundings on each term's path)
+//     det~ = fl(e1 . fl(d x e2)), |det~ + d.N| <= 5.1 u (|d| . W)         W = |e1| x |e2| with plus signs, u = 2^-24
+// and what is computed here, s_n = fma-chain(tv . N^), s_d = fma-chain(d . N^) with N^ = fl(N), is within 4.1 u of the
+// same two numbers in the same measure.  With k = 2^-19 = 32 u (> 9.2 u, 3.4x to spare), A_n = |tv| . W (W rounded
+// up on the host) and K_d = k * 2 * sum(W) (|d_i| <= 2: only applied when the walk's rays are all regular):
+//     |n~| <= |s_n| + k A_n,      |det~| >= |s_d| - K_d,      and the signs of n~, det~ are those of s_n, -s_d
+//     when |s_n| > k A_n, |s_d| > K_d.
+// t~ = fl(n~ * fl(1/det~)), so |t~| <= |n~|/|det~| (1 + u)^2:
+//     (|s_n| + k A_n)(1 + 2^-19) < |s_d| - K_d      =>  |t~| < 1            ("magnitude")
+//     s_n s_d > 0, both certified non-zero           =>  t~ < 0 or -0       ("moving away")
+// Either way the leaf rule answers None for this triangle, whatever u and v say (a |det~| < 1e-5 or a u/v reject is
+// None as well).  NaN, inf and underflow fail every comparison and leave the full test in place; the allowances
+// carry 2^-100 for flushed products.  The kernel evaluates this next to the ray's set-up, for the FIRST global
+// triangle only, and tells the walk to leave that triangle out when every one of its lanes is certified.
+__device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const float tvx = ox - g.v0[0], tvy = oy - g.v0[1], tvz = oz - g.v0[2];          // triangle.rs:78
+    const float sn = __builtin_fmaf(tvz, g.e1[2], __builtin_fmaf(tvy, g.e1[1], tvx * g.e1[0]));
+    const float an = __builtin_fmaf(fabsf(tvz), g.e2[2], __builtin_fmaf(fabsf(tvy), g.e2[1], fabsf(tvx) * g.e2[0]));
+    const float sd = __builtin_fmaf(dz, g.e1[2], __builtin_fmaf(dy, g.e1[1], dx * g.e1[0]));
+    const float kan = __builtin_fmaf(an, 0x1p-19f, 0x1p-100f);
+    const float kd = g.bmin[0];
+    const bool magnitude = (fabsf(sn) + kan) * (1.0f + 0x1p-19f) < fabsf(sd) - kd;
+    const bool away = sn * sd > 0.0f && fabsf(sn) > kan && fabsf(sd) > kd;
+    return magnitude || away;
+}
+
 // The walk itself, for one kind of box test (USE_FAST: the multiply-based conservative test, else the exact one).
+// first_global: 1 when the first global triangle has been ruled out for every lane (plane_rules_out), else 0.
 template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST>
 __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
                                             unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
-                                            uint32_t n_global)
+                                            uint32_t n_global, uint32_t first_global = 0u)
 {
     // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
     // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
@@ -661,7 +693,7 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
     if (RTX_SKIP_ROOT_TEST && n_global != 0u) {
         // the "global" triangles (scene_prep.cpp: as large as the scene, i.e. the ground) sit in the leaf at node 1:
         // tested here without its box test, then the walk starts at the root of the tree proper
-        leaf_triangles<COUNT, ANYHIT, USE_FAST>(tris, shade, 0u, n_global, r, alive, n_active, wc);
+        leaf_triangles<COUNT, ANYHIT, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
         if (ANYHIT) {
             alive = ballot(r.active);
             if (alive == 0ull) return;
@@ -700,7 +732,8 @@ template <bool COUNT, bool FAST, bool SPHERES = false, bool ANYHIT = false>
 __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
-                                            LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u)
+                                            LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
+                                            bool first_global_ruled_out = false)
 {
     unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
     // direction classes: six compares voted one by one (direction_is_regular); the hard test runs only when some
@@ -715,7 +748,8 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     if (COUNT) n_active = __popcll(alive);
     // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
     // the choice inside the loop every node paid two more taken branches on the scalar unit)
-    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
+    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global,
+                                                            (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
     else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
     return true;
 }
@@ -726,9 +760,10 @@ template <bool COUNT, bool FAST, bool SPHERES = false>
 __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                         const TriRec RTX_CONSTANT *__restrict__ tris,
                                         const ShadeRec *__restrict__ shade, uint32_t n_nodes,
-                                        LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u)
+                                        LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
+                                        bool first_global_ruled_out = false)
 {
-    return closest_hit<COUNT, FAST, SPHERES, true>(nodes, tris, shade, n_nodes, r, wc, n_global);
+    return closest_hit<COUNT, FAST, SPHERES, true>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
 }
 
 // ---------------------------------------------------------------------------------------------------

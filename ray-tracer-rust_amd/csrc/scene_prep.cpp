@@ -622,6 +622,31 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             s.tris[i] = recs[prims[i].idx];
             pos_of[prims[i].idx] = i;
         }
+        // Plane data of the global triangles (rtx_traverse.hpp: plane_rules_out).  N and W in double from the f32 edges
+        // (the products are exact there), N rounded to nearest, W upwards; K_d = 2^-19 * 2 * (Wx + Wy + Wz) + 2^-100,
+        // upwards.  Anything not comfortably finite switches the shortcut off for that triangle (K_d = inf).
+        s.global_planes.assign(s.n_global, TriRec{});
+        for (uint32_t i = 0; i < s.n_global; ++i) {
+            const TriRec &t = s.tris[i];
+            TriRec &g = s.global_planes[i];
+            const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+            double sum_w = 0.0;
+            bool fine = true;
+            for (int a = 0; a < 3; ++a) {
+                const int b = (a + 1) % 3, c = (a + 2) % 3;
+                const double n = e1[b] * e2[c] - e1[c] * e2[b];
+                const double w = std::fabs(e1[b] * e2[c]) + std::fabs(e1[c] * e2[b]);
+                g.v0[a] = t.v0[a];
+                g.e1[a] = static_cast<float>(n);
+                g.e2[a] = std::nextafter(static_cast<float>(w), std::numeric_limits<float>::infinity());
+                fine = fine && std::isfinite(w) && w < 0x1p100;
+                sum_w += static_cast<double>(g.e2[a]);
+            }
+            const double kd = 0x1p-19 * 2.0 * sum_w + 0x1p-100;
+            g.bmin[0] = fine ? std::nextafter(static_cast<float>(kd), std::numeric_limits<float>::infinity())
+                             : std::numeric_limits<float>::infinity();
+            g.idx = t.idx;
+        }
         for (NodeRec &nd : s.ref_nodes)   // leaves of the reference stream point at the same record array
             if (nd.info & kLeafFlag) {
                 const uint32_t prim = nd.info & kLeafIndexMask;

@@ -97,6 +97,9 @@ struct PreparedScene {
     // position units, rtx_traverse.hpp), so that the box test needs no per-test widening.
     float cull_delta = 0.0f;
     uint32_t n_global = 0;   // > 0: records [0, n_global) are the "global" triangles, stream = root, their leaf, the tree proper
+    // one per global triangle, in TriRec clothing: v0 = v0, e1 = fl(e1 x e2), e2 = (|e1| x |e2| with plus signs, rounded
+    // up), bmin[0] = the denominator's error allowance — what rtx_traverse.hpp: plane_rules_out needs
+    std::vector<TriRec>   global_planes;
 };
 constexpr uint32_t kMaxGlobalPrims = 8u;
 constexpr uint64_t kMaxPrimitives = 1ull << 26;   // 64 B x 2^26 = 4 GiB of records: the limit of a 32-bit byte offset

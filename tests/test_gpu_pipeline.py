@@ -154,3 +154,45 @@ def test_scenes_whose_triangles_are_all_or_partly_global(rtx, orc, samples_seede
             assert s.info()["n_global"] == want, name
             img, st = s.render_rows(stats=True)
         assert st["primary_hits"] == ost["primary_hits"] > 0 and np.array_equal(img, ref), name
+
+
+def _floor_scene(seed):
+    """A big tilted floor (a global triangle) with a soup hovering 0.3 .. 3 units over it, seen from above; the light
+    is below the floor (shadow rays cross it at t around 1: the `t < 1.0` rule of bvh.rs:64 decides), near the horizon
+    (grazing rays over the floor) or overhead."""
+    rng = np.random.default_rng(seed)
+    tilt = rng.uniform(-0.15, 0.15, size=2)
+    def height(x, z):
+        return tilt[0] * x + tilt[1] * z
+    corners = np.array([[-150.0, -120.0], [160.0, -110.0], [5.0, 170.0]]) + rng.uniform(-5, 5, size=(3, 2))
+    floor = np.array([[cx, height(cx, cz), cz] for cx, cz in corners], F).reshape(1, 9)
+    n = 90
+    c = rng.uniform(-10, 10, size=(n, 2))
+    lift = rng.choice([0.3, 0.6, 0.9, 1.0, 1.1, 1.5, 3.0], size=n) * rng.uniform(0.97, 1.03, size=n)
+    centre = np.stack([c[:, 0], height(c[:, 0], c[:, 1]) + lift, c[:, 1]], axis=1)
+    soup = (centre[:, None, :] + rng.uniform(-0.8, 0.8, size=(n, 3, 3)) * np.array([1.0, 0.15, 1.0])).astype(F)
+    e1, e2 = soup[:, 1] - soup[:, 0], soup[:, 2] - soup[:, 0]
+    soup = soup[np.linalg.norm(np.cross(e1, e2), axis=1) > 1e-3].reshape(-1, 9)
+    tris = np.concatenate([soup, floor]).astype(F)
+    rgb = rng.uniform(0.2, 1.0, size=(len(tris), 3)).astype(F)
+    where = seed % 3
+    ly = (-25.0, 1.2, 40.0)[where]
+    lx = (3.0, 60.0, -4.0)[where]
+    light = (lx - 2.0, ly, -3.0, lx + 2.0, ly, -3.0, lx, ly + (0.5 if where == 1 else 0.0), 2.0)
+    cam = dict(eye=(1.0, 30.0, 22.0), look_at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), distance=70.0, light_tri=light)
+    return tris, rgb, cam
+
+
+@pytest.mark.parametrize("seed", range(9))
+def test_plane_shortcut_of_global_triangles(rtx, orc, samples_seeded, seed):
+    """rtx_traverse.hpp: plane_rules_out skips Triangle::intersect on a global triangle when the plane alone shows that
+    the answer is None; here the answers sit on both sides of every one of its conditions."""
+    tris, rgb, cam = _floor_scene(seed)
+    W = H = 56
+    kw = dict(cam, nb_light_sample=12)
+    ref, ost = orc.Scene(W, H, tris, rgb, samples_seeded, **kw).render_rows(mode=orc.MODE_BVH)
+    with rtx.Scene(W, H, tris, rgb, samples_seeded, **kw) as s:
+        assert s.info()["n_global"] == 1
+        img, st = s.render_rows(stats=True)
+    assert st["primary_hits"] == ost["primary_hits"] > 0.5 * W * H
+    assert np.array_equal(img, ref)
