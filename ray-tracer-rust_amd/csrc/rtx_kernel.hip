@@ -747,11 +747,16 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
 
 // (Requesting the next stream record before the current one is tested — the next one visited unless an inner node
 //  fails — did not shorten this kernel: 0.1446 against 0.1416 ms for the scheduling pass of C3, same box, interleaved.)
-// primary walks of at least this many records are their tile's cost estimate themselves (0: always probe)
+// primary walks of at least this many records are their tile's cost estimate themselves (0: always probe) — in scenes
+// of at most kProbeSkipMaxNodes stream records.  There the tiles that look into the mesh are few and their two walks
+// are the pass's critical path (C3: 0.143 -> 0.110 ms); in a large scene every mesh tile's primary walk is long, the
+// pass is bound by throughput, and the probing walk's better estimate is worth more than its time (C5, 1M triangles:
+// 68.5 ms with it, 70.9 without; profiles/r01/s_ab_c5.log).
 #ifndef RTX_PROBE_SKIP_VISITS
 #define RTX_PROBE_SKIP_VISITS 64
 #endif
 constexpr uint32_t kProbeSkipVisits = RTX_PROBE_SKIP_VISITS;
+constexpr uint32_t kProbeSkipMaxNodes = 1u << 16;
 
 template <bool COUNT, bool FAST, bool SPHERES>
 __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
@@ -811,7 +816,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     unsigned long long cost = 0;
     const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
     const unsigned long long primary_walk = wc.node_visits + wc.tri_visits;
-    if (kProbeSkipVisits != 0u && primary_walk >= kProbeSkipVisits && n_hit != 0u && !(flags & 2u)) {
+    if (kProbeSkipVisits != 0u && S.n_nodes <= kProbeSkipMaxNodes && primary_walk >= kProbeSkipVisits && n_hit != 0u && !(flags & 2u)) {
         // A long primary walk: the tile looks into the mesh, and the shadow rays of what it sees start inside the
         // mesh's boxes — their walks are long too.  The primary walk's own length stands in for the probing walk,
         // which for these tiles would be the second half of the scheduling pass's critical path.
