@@ -631,6 +631,9 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
 #ifndef RTX_SKIP_ROOT_TEST
 #define RTX_SKIP_ROOT_TEST 1
 #endif
+#ifndef RTX_WALK_SINGLE_EXIT
+#define RTX_WALK_SINGLE_EXIT 1
+#endif
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ NodeRec load_node_at(const NodeRec RTX_CONSTANT *base, uint32_t index)
 {
@@ -717,7 +720,11 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
                 leaf_triangles<COUNT, ANYHIT, USE_FAST>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, alive, n_active, wc);
             if (ANYHIT) {   // lanes that found an occluder have left the walk (r.active); so does a wavefront without lanes
                 alive = ballot(r.active);
+#if RTX_WALK_SINGLE_EXIT
+                if (alive == 0ull) i = n_nodes - 1u;   // the step below ends the walk: the loop keeps ONE exit test
+#else
                 if (alive == 0ull) break;
+#endif
                 if (COUNT) n_active = __popcll(alive);
             }
         }
