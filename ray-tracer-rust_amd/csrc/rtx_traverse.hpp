@@ -631,6 +631,9 @@ __device__ __forceinline__ void leaf_spheres(const TriRec RTX_CONSTANT *__restri
 #ifndef RTX_SKIP_ROOT_TEST
 #define RTX_SKIP_ROOT_TEST 1
 #endif
+#ifndef RTX_WALK_INTEGER_FLAGS
+#define RTX_WALK_INTEGER_FLAGS 1
+#endif
 #ifndef RTX_WALK_SINGLE_EXIT
 #define RTX_WALK_SINGLE_EXIT 1
 #endif
@@ -710,10 +713,22 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
 #else
         const NodeRec cur = load_node(nodes + i);
 #endif
+#if RTX_WALK_INTEGER_FLAGS
+        // The step's two conditions as 0/1 integers in scalar registers, combined by integer instructions: as booleans
+        // the compiler turns each into a lane mask and back (s_cselect_b64, s_and_b64 with exec, ...), and the scalar
+        // unit is as loaded as the vector units here.  (s_and_b64 sets SCC when its result is not zero.)
+        const uint32_t leaf_u = cur.info >> 31;
+        const unsigned long long hits = box_mask(USE_FAST, cur, r);
+        uint32_t any_u;
+        asm("s_and_b64 vcc, %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(any_u) : "s"(hits), "s"(alive) : "vcc", "scc");
+        const bool visit = (leaf_u & any_u) != 0u, onward = (leaf_u | any_u) != 0u;
+#else
         const bool leaf = (cur.info & kLeafFlag) != 0u;
         const bool any = (box_mask(USE_FAST, cur, r) & alive) != 0ull;
+        const bool visit = leaf && any, onward = any || leaf;
+#endif
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
-        if (leaf && any) {
+        if (visit) {
             if (SPHERES && (cur.info & kSphereFlag))
                 leaf_spheres<COUNT, ANYHIT>(tris, shade, cur.info & kLeafIndexMask, cur.link, r, n_active, wc);
             else
@@ -729,7 +744,7 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
             }
         }
         // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
-        i = (any || leaf) ? i + 1u : cur.link;
+        i = onward ? i + 1u : cur.link;
     }
 }
 
