@@ -751,7 +751,7 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
 // of at most kProbeSkipMaxNodes stream records.  There the tiles that look into the mesh are few and their two walks
 // are the pass's critical path (C3: 0.143 -> 0.110 ms); in a large scene every mesh tile's primary walk is long, the
 // pass is bound by throughput, and the probing walk's better estimate is worth more than its time (C5, 1M triangles:
-// 68.5 ms with it, 70.9 without; profiles/r01/s_ab_c5.log).
+// 68.5 ms with it, 70.9 without; profiles/r01/s_ab_misc.log).
 #ifndef RTX_PROBE_SKIP_VISITS
 #define RTX_PROBE_SKIP_VISITS 64
 #endif
