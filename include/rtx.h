@@ -151,7 +151,9 @@ int rtx_scene_info(const RtxScene *scene, RtxSceneInfo *info);
 int rtx_scene_upload(RtxScene *scene, int device);
 
 /* Render rows [row0,row0+nrows) on `device` into out_rgb (nrows*width*3 bytes, host).
- * stats may be NULL; when non-NULL the launch also counts tests (slightly slower). */
+ * stats may be NULL; when non-NULL the launch also counts tests (slightly slower).
+ * One launch (this call, or one device's share of rtx_render_frame / rtx_render_tiles_device) covers at most
+ * 2^25 tiles of 8x8 pixels (2^31 pixels); beyond that the call fails with RTX_ERR_HIP: render in bands. */
 int rtx_render_rows(RtxScene *scene, int device, uint32_t row0, uint32_t nrows,
                     uint8_t *out_rgb, RtxStats *stats);
 
