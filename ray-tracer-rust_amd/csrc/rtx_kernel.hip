@@ -971,6 +971,9 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 #ifndef RTX_PLANE_SHORTCUT
 #define RTX_PLANE_SHORTCUT 1
 #endif
+#ifndef RTX_SHADE_LEAN_STEP
+#define RTX_SHADE_LEAN_STEP 1
+#endif
 #ifndef RTX_SHADE_WAVES_PER_SIMD
 #define RTX_SHADE_WAVES_PER_SIMD 8
 #endif
@@ -1075,7 +1078,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         const bool no_ground = have_plane &&
                             (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
-                        const bool ok = any_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
+                        const bool ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
                         if (!ok && lane == 0) l_ctl[1] = 1u;
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
                         else shadow_result(l_hit, l_res, res_stride, sr);

@@ -685,7 +685,7 @@ __device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float
 
 // The walk itself, for one kind of box test (USE_FAST: the multiply-based conservative test, else the exact one).
 // first_global: 1 when the first global triangle has been ruled out for every lane (plane_rules_out), else 0.
-template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST>
+template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST, bool LEAN = false>
 __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
@@ -744,13 +744,24 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
             }
         }
         // after a leaf (visited or not) and into a passed inner node: next record in pre-order; else skip the subtree
+#if RTX_WALK_INTEGER_FLAGS
+        if (LEAN) {   // the same select with SCC taken from the OR itself (one scalar instruction less per record); only
+                      // where the kernel has scalar registers to spare: probe_kernel, at 103, does not build with it
+            uint32_t next;
+            asm("s_or_b32 %0, %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=&s"(next) : "s"(leaf_u), "s"(any_u), "s"(i + 1u), "s"(cur.link) : "scc");
+            i = next;
+        } else {
+            i = onward ? i + 1u : cur.link;
+        }
+#else
         i = onward ? i + 1u : cur.link;
+#endif
     }
 }
 
 // SPHERES = false compiles the Sphere arm out: scenes without spheres (every BASELINE configuration) run the
 // triangle-only kernel, whose register allocation the extra arm would otherwise push into scratch.
-template <bool COUNT, bool FAST, bool SPHERES = false, bool ANYHIT = false>
+template <bool COUNT, bool FAST, bool SPHERES = false, bool ANYHIT = false, bool LEAN = false>
 __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
@@ -770,7 +781,7 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     if (COUNT) n_active = __popcll(alive);
     // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
     // the choice inside the loop every node paid two more taken branches on the scalar unit)
-    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global,
+    if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true, LEAN>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global,
                                                             (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
     else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
     return true;
@@ -778,14 +789,14 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
 
 // any_hit: the walk of a shadow ray.  r.limit = distance to the light point; on return r.best_idx != kNone iff the
 // sample is occluded (see candidate_occludes), r.active is consumed.
-template <bool COUNT, bool FAST, bool SPHERES = false>
+template <bool COUNT, bool FAST, bool SPHERES = false, bool LEAN = false>
 __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                         const TriRec RTX_CONSTANT *__restrict__ tris,
                                         const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                         LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
                                         bool first_global_ruled_out = false)
 {
-    return closest_hit<COUNT, FAST, SPHERES, true>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
+    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
 }
 
 // ---------------------------------------------------------------------------------------------------
