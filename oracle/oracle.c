@@ -660,6 +660,7 @@ typedef struct {
     const orc_scene *s;
     int mode;
     uint32_t row0, nrows;
+    uint32_t col0, ncols, chunk;   /* window columns [col0, col0+ncols), pixels claimed at a time */
     uint8_t *out;
     uint32_t *out_tri;
     float *out_lin;
@@ -673,19 +674,20 @@ static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     const orc_scene *s = j->s;
-    const uint32_t chunks_per_row = (s->width + ORC_CHUNK - 1) / ORC_CHUNK;
+    const uint32_t chunks_per_row = (j->ncols + j->chunk - 1) / j->chunk;
     const uint32_t n_chunks = chunks_per_row * j->nrows;
     for (;;) {
         uint32_t ck = __atomic_fetch_add(j->next_row, 1, __ATOMIC_RELAXED);
         if (ck >= n_chunks) break;
         uint32_t r = ck / chunks_per_row;
-        uint32_t x0 = (ck % chunks_per_row) * ORC_CHUNK;
-        uint32_t x1 = x0 + ORC_CHUNK < s->width ? x0 + ORC_CHUNK : s->width;
+        uint32_t x0 = (ck % chunks_per_row) * j->chunk;
+        uint32_t x1 = x0 + j->chunk < j->ncols ? x0 + j->chunk : j->ncols;
         uint32_t py = j->row0 + r;
-        for (uint32_t px = x0; px < x1; px++) {
+        for (uint32_t wx = x0; wx < x1; wx++) {
             int32_t ft;
+            const uint32_t px = j->col0 + wx;
             v3 c = render_pixel(s, j->mode, px, py, &j->pc, &ft);
-            size_t p = (size_t)r * s->width + px;
+            size_t p = (size_t)r * j->ncols + wx;
             float cc[3] = { c.x, c.y, c.z };
             if (j->out) orc_color_to_rgb8(cc, j->out + 3 * p);  /* color.rs:28-33 */
             if (j->out_tri) j->out_tri[p] = ft < 0 ? 0xFFFFFFFFu : (uint32_t)ft;
@@ -695,10 +697,11 @@ static void *worker(void *arg)
     return NULL;
 }
 
-int orc_render_rows_ex(const orc_scene *s, int mode, uint32_t row0, uint32_t nrows, int nthreads,
-                       uint8_t *out_rgb, uint32_t *out_tri, float *out_lin, orc_stats *stats)
+static int render_window(const orc_scene *s, int mode, uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                         uint32_t chunk, int nthreads, uint8_t *out_rgb, uint32_t *out_tri, float *out_lin,
+                         orc_stats *stats)
 {
-    if (!s || row0 + nrows > s->height) return -1;
+    if (!s || (uint64_t)row0 + nrows > s->height || (uint64_t)col0 + ncols > s->width) return -1;
     if (mode == ORC_MODE_BVH && !s->nodes) return -2;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
@@ -708,6 +711,7 @@ int orc_render_rows_ex(const orc_scene *s, int mode, uint32_t row0, uint32_t nro
     double t0 = now_ms();
     for (int i = 0; i < nthreads; i++) {
         jobs[i].s = s; jobs[i].mode = mode; jobs[i].row0 = row0; jobs[i].nrows = nrows;
+        jobs[i].col0 = col0; jobs[i].ncols = ncols; jobs[i].chunk = chunk;
         jobs[i].out = out_rgb; jobs[i].out_tri = out_tri; jobs[i].out_lin = out_lin;
         jobs[i].next_row = &next_row;
         if (nthreads == 1) worker(&jobs[i]);
@@ -734,6 +738,22 @@ int orc_render_rows_ex(const orc_scene *s, int mode, uint32_t row0, uint32_t nro
     }
     free(jobs); free(th);
     return 0;
+}
+
+int orc_render_rows_ex(const orc_scene *s, int mode, uint32_t row0, uint32_t nrows, int nthreads,
+                       uint8_t *out_rgb, uint32_t *out_tri, float *out_lin, orc_stats *stats)
+{
+    if (!s) return -1;
+    return render_window(s, mode, 0, row0, s->width, nrows, ORC_CHUNK, nthreads, out_rgb, out_tri, out_lin, stats);
+}
+
+/* A window of the frame, columns [col0, col0+ncols) x rows [row0, row0+nrows), packed row-major into out_rgb
+ * (nrows*ncols*3): the same render_pixel per pixel, threads claim one pixel at a time.  For scenes where a whole
+ * row is out of the CPU's reach (BASELINE configs[4]: 10^6 primitives in leaf-gated brute-force mode). */
+int orc_render_window(const orc_scene *s, int mode, uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                      int nthreads, uint8_t *out_rgb, orc_stats *stats)
+{
+    return render_window(s, mode, col0, row0, ncols, nrows, 1u, nthreads, out_rgb, NULL, NULL, stats);
 }
 
 int orc_render_rows(const orc_scene *s, int mode, uint32_t row0, uint32_t nrows, int nthreads,

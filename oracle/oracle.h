@@ -122,6 +122,10 @@ int  orc_render_rows(const orc_scene *s, int mode, uint32_t row0, uint32_t nrows
 int  orc_render_rows_ex(const orc_scene *s, int mode, uint32_t row0, uint32_t nrows, int nthreads,
                         uint8_t *out_rgb, uint32_t *out_tri, float *out_lin, orc_stats *stats);
 
+/* a window of the frame: columns [col0,col0+ncols) x rows [row0,row0+nrows) packed into out_rgb (nrows*ncols*3) */
+int  orc_render_window(const orc_scene *s, int mode, uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                       int nthreads, uint8_t *out_rgb, orc_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

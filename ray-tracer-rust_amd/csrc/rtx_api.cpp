@@ -108,13 +108,19 @@ int upload_vec(void **dst, const std::vector<T> &v, size_t pad_bytes = 0)
     return RTX_OK;
 }
 
+// librtx.so runs one pipeline.  Only the ablation build (librtx_ablation.so, -DRTX_ABLATION=1: A/B tools and the
+// variant-equality test) lets RTX_VARIANT pick another one, read once per process.
 uint32_t kernel_variant()
 {
+#if RTX_ABLATION
     static const uint32_t v = [] {
         const char *e = std::getenv("RTX_VARIANT");
         return e ? static_cast<uint32_t>(std::atoi(e)) & rtx::kVariantMask : rtx::kDefaultVariant;
     }();
     return v;
+#else
+    return rtx::kDefaultVariant;
+#endif
 }
 
 // caller holds st.mu and has the device current
@@ -517,6 +523,11 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     if (!scene || !tiles_x || !tiles_y) return RTX_ERR_BAD_ARG;
     const uint32_t H = scene->prep.height;
     if (row0 > H || nrows > H - row0 || nrows == 0) return RTX_ERR_BAD_ARG;
+#if !RTX_ABLATION
+    // the per-tile instrumentation lives in the fused kernel, which only librtx_ablation.so carries
+    (void)device; (void)out; (void)out_tiles;
+    return RTX_ERR_UNSUPPORTED;
+#else
     DeviceState *st;
     int rc = get_state(scene, device, &st);
     if (rc != RTX_OK) return rc;
@@ -546,6 +557,7 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     for (size_t t = 0; t < n; ++t)   // the kernel keeps the earliest start as max(~t)
         out[rtx::kWaveProfWords * t + 2] = ~out[rtx::kWaveProfWords * t + 2];
     return RTX_OK;
+#endif
 }
 
 int rtx_launch_timings(RtxScene *scene, int device, int max_launches, float *schedule_ms, float *shade_ms)

@@ -71,6 +71,7 @@ struct StreamWorkspace {
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets; };
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);
 constexpr uint32_t kCostBuckets = 64u;
+constexpr uint32_t kStreamCtrWords = 4u;   // counters of the streamed (ablation) pipeline
 
 // counters layout (uint64 x 8): 0 primary_hits, 1 box_tests, 2 tri_tests, 3 wave_node_visits, 4 wave_tri_visits,
 // 5 tiles re-rendered by reference_tiles_kernel, 6 / 7 the part of 3 / 4 spent in probe_kernel (primary rays)

@@ -558,8 +558,12 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
         } else {
             uint32_t leaf_max = d.leaf_max ? d.leaf_max : 4;
             double box_cost = 1.0;
+            bool global_leaf = true;
+#if RTX_ABLATION   // sweeps of tools/sweep.py; librtx.so takes these from RtxSceneDesc (leaf_max) or not at all
             if (const char *e = std::getenv("RTX_LEAF_MAX")) leaf_max = std::max(1, std::atoi(e));
-            if (const char *e = std::getenv("RTX_SAH_BOX_COST")) box_cost = std::atof(e);
+            if (const char *e = std::getenv("RTX_SAH_BOX_COST")) { const double c = std::atof(e); if (c > 0.0) box_cost = c; }
+            global_leaf = !std::getenv("RTX_NO_GLOBAL_LEAF");
+#endif
             // "Global" primitives: triangles whose own box is about as large as the scene's (the ground of main()).
             // Every ray meets such a box, so testing it is wasted work, and as a child of the root it makes the root's
             // other child — the actual scene — one level deeper for everybody.  They go into the first leaf, which
@@ -570,7 +574,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             all.reset();
             for (const Prim &p : prims) all.grow(p.lo, p.hi);
             const double scene_area = all.half_area();
-            if (scene_area > 0 && !std::getenv("RTX_NO_GLOBAL_LEAF")) {
+            if (scene_area > 0 && global_leaf) {
                 auto is_global = [&](const Prim &p) {
                     Box b;
                     std::memcpy(b.lo, p.lo, 12);

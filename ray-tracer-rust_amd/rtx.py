@@ -14,12 +14,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx.so")
+# librtx.so is the product.  RTX_PY_ABLATION=1 makes THIS BINDING load librtx_ablation.so instead (the same sources
+# built with -DRTX_ABLATION=1: every earlier kernel form, selectable through RTX_VARIANT) — for tools/ and the
+# variant-equality test only; the library itself reads no environment variable.
+LIB_PATH = os.path.join(_HERE, "librtx_ablation.so" if os.environ.get("RTX_PY_ABLATION") == "1" else "librtx.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        "librtx.so is not built (%s). Build it with: python -c 'import __graft_entry__ as g; g.build()' "
-        "or make -C ray-tracer-rust_amd/csrc" % LIB_PATH)
+        "%s is not built. Build it with: python -c 'import __graft_entry__ as g; g.build()' "
+        "or make -C ray-tracer-rust_amd/csrc [ablation]" % LIB_PATH)
 
 _lib = C.CDLL(LIB_PATH)
 
@@ -376,7 +379,8 @@ class Scene:
 
     def wave_profile(self, row0=0, nrows=None, device=0):
         """Diagnostics: [tiles_y, tiles_x, 8] uint64 {node fetches, triangle fetches, start, end, primary phase,
-        shadow phase (slowest wavefront), accumulation phase, -}; times in 100 MHz ticks."""
+        shadow phase (slowest wavefront), accumulation phase, -}; times in 100 MHz ticks.  Ablation build only
+        (RTX_PY_ABLATION=1): librtx.so answers ERR_UNSUPPORTED."""
         if nrows is None:
             nrows = self.height - row0
         tx, ty = C.c_uint32(), C.c_uint32()

@@ -85,6 +85,9 @@ def lib():
     L.orc_render_rows_ex.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.orc_render_rows_ex.restype = C.c_int
+    L.orc_render_window.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                    C.c_void_p, C.POINTER(Stats)]
+    L.orc_render_window.restype = C.c_int
     L.orc_gen_samples.argtypes = [C.c_uint64, C.c_uint32, f32p]
     L.orc_import_obj.argtypes = [C.c_char_p, C.POINTER(f32p)]
     L.orc_import_obj.restype = C.c_int
@@ -216,6 +219,17 @@ class Scene:
         if want_lin:
             res.append(lin)
         return tuple(res)
+
+    def render_window(self, col0, row0, ncols, nrows, mode=MODE_BVH, nthreads=None):
+        """Columns [col0, col0+ncols) x rows [row0, row0+nrows) of the frame -> (uint8 [nrows, ncols, 3], stats)."""
+        if nthreads is None:
+            nthreads = os.cpu_count() or 1
+        img = np.zeros((nrows, ncols, 3), dtype=np.uint8)
+        st = Stats()
+        rc = lib().orc_render_window(self.h, mode, col0, row0, ncols, nrows, nthreads, img.ctypes.data, C.byref(st))
+        if rc != 0:
+            raise RuntimeError("orc_render_window -> %d" % rc)
+        return img, st.asdict()
 
 
 def default_scene(obj_names, width, height, samples, **kw):

@@ -1,9 +1,10 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Every render goes through the C ABI
 (include/rtx.h) into the HIP kernel; the CPU oracle is only the checker.
 
-Bar (BASELINE.json north_star): integer indexing bit-exact, per-channel |delta| <= 1 LSB.
-The kernel does not evaluate powf (the byte steps are located with the host libm), so the
-expected difference is 0; the tests assert <= 1 and report the count of non-zero pixels.
+Bar: BASELINE.json's north_star allows per-channel |delta| <= 1 LSB for the float shading (integer indexing
+bit-exact).  The kernel does not evaluate powf (the byte steps are located with the host libm) and restates the
+reference's f32 operations one rounding at a time, so this suite demands MORE than the north_star: every byte equal
+(TOL_LSB = 0).
 """
 import importlib
 import json
@@ -17,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-TOL_LSB = 1   # per-channel tolerance stated by BASELINE.json's north_star
+TOL_LSB = 0   # north_star allows 1; DESIGN.md section 2 claims exactness, so exactness is what is asserted
 
 
 @pytest.fixture(scope="module")
@@ -188,10 +189,20 @@ def test_hits_closer_than_one_are_ignored(rtx, orc, samples_seeded):
     assert img[..., 0].max() == 0        # nothing red
 
 
-def test_full_size_1080p_properties(rtx, orc, samples_seeded, samples_half):
-    """BASELINE configs[1,2] at full size: counts equal the oracle-pinned probe numbers, oracle parity on
-    sampled row bands, and partition invariance (size-independent property)."""
+def test_full_size_1080p_whole_frame_against_the_oracle(rtx, orc, samples_seeded, samples_half):
+    """BASELINE configs[2] (the metric's configuration) at full size, seeded table: EVERY byte of the 1920x1080 frame
+    against the oracle's faithful BVH (about 30 s of oracle time on the box's cores), plus the integer counts.
+    configs[1,2] with the constant table: counts equal the survey's probe numbers (pinned to the oracle in
+    tests/test_oracle_numpy.py), partition invariance, sampled oracle rows."""
     W, H = 1920, 1080
+    with rtx.default_scene([model("big_bunny.obj")], W, H, samples_seeded) as s:
+        img2, st2 = s.render_rows(stats=True)
+        assert np.array_equal(s.render_frame((0,), 16), img2)
+    ref2, ost2 = orc.default_scene(["big_bunny.obj"], W, H, samples_seeded).render_rows(mode=orc.MODE_BVH)
+    assert st2["primary_hits"] == ost2["primary_hits"] and st2["redo_tiles"] == 0
+    assert st2["rays"] == W * H + 100 * ost2["primary_hits"]
+    assert ost2["nonfinite_t"] == 0 and ost2["assert_tmin_gt_tmax"] == 0
+    assert assert_image_close(img2, ref2, "1080p seeded, whole frame") == 0
     with rtx.default_scene([model("big_bunny.obj")], W, H, samples_half) as s:
         img, st = s.render_rows(stats=True)
         assert st["primary_hits"] == 37005 + 999919        # SURVEY §8(d), reproduced by the oracle in test_oracle_numpy
@@ -202,17 +213,71 @@ def test_full_size_1080p_properties(rtx, orc, samples_seeded, samples_half):
     for row0, n in ((500, 2), (560, 2), (664, 2), (1078, 2)):
         ref, _ = osc.render_rows(row0, n, mode=orc.MODE_BVH)
         assert_image_close(img[row0:row0 + n], ref, "1080p half rows %d" % row0)
-    with rtx.default_scene([model("big_bunny.obj")], W, H, samples_seeded) as s:
-        img2 = s.render_rows()
-    osc2 = orc.default_scene(["big_bunny.obj"], W, H, samples_seeded)
-    for row0, n in ((543, 1), (600, 2), (700, 1)):
-        ref, _ = osc2.render_rows(row0, n, mode=orc.MODE_BVH)
-        assert_image_close(img2[row0:row0 + n], ref, "1080p seeded rows %d" % row0)
     with rtx.default_scene([model("bunny.obj")], W, H, samples_half) as s:     # configs[1]
         img3, st3 = s.render_rows(stats=True)
     assert st3["primary_hits"] == 1022304
     ref, _ = orc.default_scene(["bunny.obj"], W, H, samples_half).render_rows(800, 2, mode=orc.MODE_BVH)
     assert_image_close(img3[800:802], ref, "bunny.obj 1080p")
+
+
+def test_synthetic_1m_triangles_4096_square_full_size(rtx, orc, samples_seeded):
+    """BASELINE configs[4] at ITS size: 1,000,000 random triangles + the ground (1,000,001 primitives), 4096x4096,
+    through rtx_render_tiles_device (the entry point bench.py uses).
+      * every tile rendered exactly once: two buffers pre-filled with different bytes come out identical;
+      * integer bound: lit (non-black) pixels <= primary hits, and the hit count of an interleaved 4-way partition
+        of the frame sums to the whole frame's, its bytes scatter back to the same frame (size-independent property);
+      * no tile went through the reference re-render (no -0.0 direction in this configuration);
+      * oracle parity where the CPU can reach: three 64-pixel row segments — through the soup's silhouette, inside
+        its shadow on the ground, open ground — in leaf-gated brute-force mode (the reference's O(n^2) tree is not
+        buildable at 10^6 primitives; that mode equals the faithful BVH for every ray without a -0.0 direction
+        component, DESIGN.md section 2, and exact ties are asserted absent)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    W = H = 4096
+    tris, rgb = rtx.synthetic_primitives(1000000)
+    assert len(tris) == 1000001
+    stream = torch.cuda.current_stream().cuda_stream
+    with rtx.Scene(W, H, tris, rgb, samples_seeded) as s:
+        info = s.info()
+        assert info["n_tris"] == 1000001 and info["n_ref_nodes"] == 0 and info["n_global"] == 1
+        nbytes = s.tiles_bytes(0, 1, 8)
+        assert nbytes == W * H * 3
+        ctr = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        frames = []
+        for filler in (0xAA, 0x55):
+            buf = torch.full((nbytes,), filler, dtype=torch.uint8, device="cuda:0")
+            s.render_tiles_device(0, 0, 1, 8, buf.data_ptr(), nbytes, stream, ctr.data_ptr() if filler == 0xAA else None)
+            torch.cuda.synchronize()
+            frames.append(buf.cpu().numpy().reshape(H, W, 3))
+            del buf
+        hits, redo = int(ctr[0]), int(ctr[5])
+        assert np.array_equal(frames[0], frames[1])
+        frame = frames[0]
+        del frames
+        lit = int((frame.reshape(-1, 3).max(axis=1) > 0).sum())
+        assert redo == 0 and 0.5 * hits < lit <= hits
+        # interleaved partition, as four ranks would render it
+        world, tile_rows, part_hits = 4, 8, 0
+        again = np.zeros_like(frame)
+        for rank in range(world):
+            nb = s.tiles_bytes(rank, world, tile_rows)
+            buf = torch.full((nb,), 0x33, dtype=torch.uint8, device="cuda:0")
+            c = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+            s.render_tiles_device(0, rank, world, tile_rows, buf.data_ptr(), nb, stream, c.data_ptr())
+            torch.cuda.synchronize()
+            part_hits += int(c[0])
+            rtx.scatter_tiles(again, buf.cpu().numpy().reshape(-1, W, 3), rank, world, tile_rows)
+            del buf
+        assert part_hits == hits and np.array_equal(again, frame)
+    osc = orc.Scene(W, H, tris, rgb, samples_seeded, build_bvh=False)
+    # the soup fills x 1820..2280 / y 1880..2350 or so of the frame (the big_bunny box seen by the default camera)
+    for col0, row in ((1790, 2100), (2048, 2480), (300, 3900)):
+        ref, ost = osc.render_window(col0, row, 64, 1, mode=orc.MODE_LEAFBOX)
+        assert ost["nonfinite_t"] == 0
+        got = frame[row:row + 1, col0:col0 + 64]
+        print("configs[4] segment x %d..%d y %d: oracle hits %d, box tests %d" % (col0, col0 + 63, row, ost["primary_hits"], ost["slab_tests"]))
+        assert np.array_equal(got, ref), "segment at x=%d y=%d" % (col0, row)
 
 
 def _random_soup(rng, n, lattice):
@@ -286,7 +351,9 @@ def test_synthetic_soup_beyond_reference_tree(rtx, orc, samples_seeded):
 def test_every_kernel_variant_gives_the_same_bytes(samples_seeded):
     """The kernel variants kept for ablation (exact vs multiply-based culling, 1/2/4/8 wavefronts per tile, the
     streamed three-kernel pipeline, two rays per lane with packed f32) must all reproduce the golden image.
-    RTX_VARIANT is read once per process, so each variant renders in its own child process (one at a time)."""
+    They live in librtx_ablation.so only (RTX_PY_ABLATION=1 makes the Python binding load it); RTX_VARIANT is read
+    once per process there, so each variant renders in its own child process (one at a time).  librtx.so itself has
+    one pipeline and reads no environment variable (checked on the CPU: tests/test_host_prep.py)."""
     import subprocess
     import sys
     ref, case = golden("c1b_bigbunny_256_seed")
@@ -300,7 +367,7 @@ def test_every_kernel_variant_gives_the_same_bytes(samples_seeded):
     import hashlib
     want = hashlib.sha1(np.ascontiguousarray(ref).tobytes()).hexdigest()
     for variant in (0, 1, 2, 3, 5, 7, 8, 9, 25, 34, 35):
-        env = dict(os.environ, RTX_VARIANT=str(variant))
+        env = dict(os.environ, RTX_VARIANT=str(variant), RTX_PY_ABLATION="1")
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
         assert line, (variant, out.stderr[-800:])

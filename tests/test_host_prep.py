@@ -35,6 +35,25 @@ def test_library_exports_every_declared_symbol(rtx):
     assert rtx.device_count() >= 0
 
 
+def test_product_library_has_one_pipeline_and_reads_no_environment(rtx):
+    """librtx.so must behave the same whatever the caller's environment holds: it imports no getenv, and its device
+    code object carries the five kernels of the shipped pipeline only.  The earlier kernel forms and their
+    RTX_VARIANT / RTX_LEAF_MAX / ... switches exist in librtx_ablation.so (make ablation) and nowhere else."""
+    lib = os.path.join(ROOT, "ray-tracer-rust_amd", "librtx.so")
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    blob = open(lib, "rb").read()
+    names = lambda b: set(m.decode() for m in re.findall(rb"_ZN3rtx\d+([a-z0-9_]+_kernel)I?", b)
+                          if not m.startswith(b"__device_stub__"))
+    kernels = names(blob)
+    assert kernels == {"probe_kernel", "count_classes_kernel", "order_tiles_kernel", "shade_tiles_kernel",
+                       "reference_tiles_kernel"}, kernels
+    abl = os.path.join(ROOT, "ray-tracer-rust_amd", "librtx_ablation.so")
+    assert os.path.exists(abl), "make -C ray-tracer-rust_amd/csrc ablation"
+    more = names(open(abl, "rb").read())
+    assert kernels < more and "trace_shade_kernel" in more
+
+
 def test_no_device_means_error_not_fallback(rtx, samples_half):
     if rtx.device_count() > 0:
         pytest.skip("a GPU is present")

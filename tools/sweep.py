@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development tool (not part of the product or the tests): time kernel variants and build options
+"""Development tool (not part of the product or the tests; needs librtx_ablation.so and RTX_PY_ABLATION=1): time kernel variants and build options
 on one GPU, each in its own process because RTX_VARIANT / RTX_LEAF_MAX are read once per process.
 
     python tools/sweep.py variants            # RTX_VARIANT 0..7 on big_bunny 1080p
@@ -43,7 +43,7 @@ def child(width, height, reps):
 
 
 def run_child(env_extra, width=1920, height=1080, reps=5):
-    env = dict(os.environ)
+    env = dict(os.environ, RTX_PY_ABLATION="1")   # the variants and build knobs live in librtx_ablation.so
     env.update(env_extra)
     out = subprocess.run([sys.executable, __file__, "child", str(width), str(height), str(reps)], env=env,
                          capture_output=True, text=True, timeout=600)
