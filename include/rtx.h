@@ -194,6 +194,13 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
 #define RTX_TIMING_RING 64
 int rtx_launch_timings(RtxScene *scene, int device, int max_launches, float *schedule_ms, float *shade_ms);
 
+/* Diagnostics: the tile descriptors the most recent launch on `device` left in the library's workspace, one per 8x8
+ * tile of that launch, row-major, four uint32 each: {cost class (0xFFFFFFFF: finished by the scheduling pass), primary
+ * hits, flags (bit 0 sample-major numbering, bit 1 re-rendered by the reference walk, bits 8-15 entries of the tile's
+ * cut), reserved}.  Call with out == NULL to get the count.  Blocks until the device is idle.  Returns the number of
+ * tiles written (<= max_tiles) or a negative RtxError. */
+int rtx_debug_tile_descs(RtxScene *scene, int device, uint32_t *out, size_t max_tiles);
+
 const char *rtx_strerror(int err);
 int rtx_last_hip_error(void);
 

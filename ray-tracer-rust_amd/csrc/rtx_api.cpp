@@ -35,7 +35,7 @@ thread_local int g_last_hip_error = 0;
 struct DeviceState {
     std::mutex mu;
     bool uploaded = false;
-    void *nodes = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr;
+    void *nodes = nullptr, *wide = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr, *light_boxes = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_out = nullptr;
@@ -47,6 +47,7 @@ struct DeviceState {
     rtx::StreamWorkspaceBytes ws_cap{};
     uint8_t *h_stage = nullptr;   // pinned
     size_t h_stage_cap = 0;
+    size_t last_tiles = 0;        // tiles of the most recent launch (rtx_debug_tile_descs)
     hipEvent_t ring[RTX_TIMING_RING][3] = {};   // launch start / end of the scheduling pass / launch end (rtx_launch_timings)
     unsigned long long launches = 0;
 };
@@ -131,6 +132,13 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     int rc;
     const float inflate = RTX_CULL_INFLATED ? p.cull_delta : 0.0f;
     if ((rc = upload_vec(&st.nodes, rtx::nodes_in_device_order(p.nodes, inflate), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
+    {   // the wide nodes' boxes move outwards like the binary stream's (cull_delta)
+        std::vector<rtx::WideNode> w = p.wide;
+        for (rtx::WideNode &n : w)
+            for (int c = 0; c < 4; ++c)
+                for (int a = 0; a < 3; ++a) { n.box[c][a] -= inflate; n.box[c][3 + a] += inflate; }
+        if ((rc = upload_vec(&st.wide, w)) != RTX_OK) return rc;
+    }
     if (!p.ref_nodes.empty() &&
         (rc = upload_vec(&st.ref_nodes, rtx::nodes_in_device_order(p.ref_nodes), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.tris, p.tris)) != RTX_OK) return rc;
@@ -138,6 +146,7 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
     if ((rc = upload_vec(&st.samples, p.samples)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.lights, p.light_points)) != RTX_OK) return rc;
     if (!p.global_planes.empty() && (rc = upload_vec(&st.planes, p.global_planes)) != RTX_OK) return rc;
+    if ((rc = upload_vec(&st.light_boxes, p.light_boxes)) != RTX_OK) return rc;
     RTX_HIP(hipMalloc(&st.thr, sizeof(p.gamma_thr)));
     RTX_HIP(hipMemcpy(st.thr, p.gamma_thr, sizeof(p.gamma_thr), hipMemcpyHostToDevice));
     RTX_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_counters), rtx::kNumCounters * sizeof(unsigned long long)));
@@ -155,6 +164,8 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     const rtx::PreparedScene &p = scene->prep;
     rtx::DeviceScene S;
     S.nodes = static_cast<const rtx::NodeRec *>(st.nodes);
+    S.wide = static_cast<const rtx::WideNode *>(st.wide);
+    S.n_wide = static_cast<uint32_t>(p.wide.size());
     S.ref_nodes = static_cast<const rtx::NodeRec *>(st.ref_nodes);
     S.n_ref_nodes = static_cast<uint32_t>(p.ref_nodes.size());
     S.tris = static_cast<const rtx::TriRec *>(st.tris);
@@ -163,6 +174,8 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     S.light_points = static_cast<const float *>(st.lights);
     S.planes = static_cast<const rtx::TriRec *>(st.planes);
     S.gamma_thr = static_cast<const float *>(st.thr);
+    S.light_boxes = static_cast<const float *>(st.light_boxes);
+    S.shaft_delta = p.shaft_delta;
     S.n_nodes = static_cast<uint32_t>(p.nodes.size());
     S.n_samples = p.n_samples;
     S.width = p.width;
@@ -237,6 +250,8 @@ int ensure_stream_ws(DeviceState &st, const rtx::DeviceScene &S, const rtx::Tile
     if (need.acc && (rc = grow_buffer(&st.ws.acc, &st.ws_cap.acc, need.acc)) != RTX_OK) return rc;
     if ((rc = grow_buffer(&st.ws.ctr, &st.ws_cap.ctr, need.ctr)) != RTX_OK) return rc;
     if (need.buckets && (rc = grow_buffer(&st.ws.buckets, &st.ws_cap.buckets, need.buckets)) != RTX_OK) return rc;
+    if (need.cut && (rc = grow_buffer(&st.ws.cut, &st.ws_cap.cut, need.cut)) != RTX_OK) return rc;
+    st.last_tiles = need.tiles / sizeof(rtx::TileDesc);
     *out = &st.ws;
     return RTX_OK;
 }
@@ -340,8 +355,8 @@ void rtx_scene_destroy(RtxScene *scene)
         DeviceGuard g(kv.first);
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
-        void *bufs[] = {st.nodes, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.d_out, st.d_counters, st.d_redo,
-                        st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr, st.ws.buckets};
+        void *bufs[] = {st.nodes, st.wide, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.light_boxes, st.d_out, st.d_counters, st.d_redo,
+                        st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr, st.ws.buckets, st.ws.cut};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);
         if (st.ev0) (void)hipEventDestroy(st.ev0);
@@ -558,6 +573,22 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
         out[rtx::kWaveProfWords * t + 2] = ~out[rtx::kWaveProfWords * t + 2];
     return RTX_OK;
 #endif
+}
+
+int rtx_debug_tile_descs(RtxScene *scene, int device, uint32_t *out, size_t max_tiles)
+{
+    if (!scene) return RTX_ERR_BAD_ARG;
+    DeviceState *st;
+    int rc = get_state(scene, device, &st);
+    if (rc != RTX_OK) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    if (!out) return static_cast<int>(st->last_tiles);
+    DeviceGuard g(device);
+    RTX_HIP(g.status());
+    const size_t n = st->last_tiles < max_tiles ? st->last_tiles : max_tiles;
+    RTX_HIP(hipDeviceSynchronize());
+    if (n) RTX_HIP(hipMemcpy(out, st->ws.tiles, n * sizeof(rtx::TileDesc), hipMemcpyDeviceToHost));
+    return static_cast<int>(n);
 }
 
 int rtx_launch_timings(RtxScene *scene, int device, int max_launches, float *schedule_ms, float *shade_ms)

@@ -19,6 +19,7 @@ namespace rtx {
 // Passed by value (kernarg segment -> SGPRs).
 struct DeviceScene {
     const NodeRec  *nodes;         // (n_nodes + 1) x 32 B, pre-order with skip links; last = zeroed sentinel
+    const WideNode *wide;          // n_wide x 128 B: the same tree with four children per node, what the walks run on (root first)
     const NodeRec  *ref_nodes;     // (n_ref_nodes + 1) x 32 B: the reference's own tree, or NULL
     const TriRec   *tris;          // n_tris x 64 B, leaf order
     const ShadeRec *shade;         // n_tris x 32 B, caller order
@@ -26,13 +27,15 @@ struct DeviceScene {
     const float2   *samples;       // n_samples x (s.0, s.1)
     const float    *light_points;  // nb_ray x nb_light x 3
     const float    *gamma_thr;     // 256
-    uint32_t n_nodes, n_ref_nodes, n_samples;
+    const float    *light_boxes;   // nb_ray x 6: bounding box (lo xyz, hi xyz) of the light points of primary ray r
+    uint32_t n_nodes, n_ref_nodes, n_samples, n_wide;
     uint32_t width, height;
     uint32_t nb_ray, nb_light;
     uint32_t n_global;             // > 0: primitive records [0, n_global) are tested by every walk up front, the tree proper starts at node 2
     uint32_t n_spheres;            // > 0: some leaves carry kSphereFlag: the fused kernel with the Sphere arm compiled in is launched
     float eye[3], cu[3], cv[3], cw[3];
     float distance;
+    float shaft_delta;             // margin of the tile shaft test in position units (PreparedScene::shaft_delta)
 };
 
 // Which rows a launch renders: local row ly (0 <= ly < local_rows) is row
@@ -51,7 +54,8 @@ struct TileSpec {
 struct TileDesc {
     uint32_t first;      // streamed pipeline: first hit record / result row block of the tile; probe pipeline: cost class
     uint32_t n_hit;
-    uint32_t flags;      // bit 0: number the tile's rays sample-major; bit 1: queued for the reference re-render
+    uint32_t flags;      // bit 0: number the tile's rays sample-major; bit 1: queued for the reference re-render;
+                         // bits 8-15: entries of the tile's cut (StreamWorkspace::cut)
     uint32_t pad;
 };
 struct HitRec {          // 48 B
@@ -67,8 +71,21 @@ struct StreamWorkspace {
     float    *acc;       // tiles x 64 x 3 running sums, only when nb_ray > 1
     uint32_t *ctr;       // hit count, chunk count, chunk cursor
     uint32_t *buckets;   // probe pipeline: tile order by cost class (layout: order_tiles_kernel)
+    uint2    *cut;       // tiles x kMaxCut: the subtrees (record ranges [x, y) of the node stream; wide build: x = byte offset of
+                         // a wide node) the tile's shaft towards the light can touch — written by probe_kernel, walked
+                         // by shade_tiles_kernel
 };
-struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets; };
+struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets, cut; };
+#ifndef RTX_MAX_CUT
+#define RTX_MAX_CUT 16
+#endif
+// 1: the kernels walk the four-child form of the tree (rtx_traverse.hpp: walk_wide) instead of the binary stream.  Same
+// bytes, measured slower on every configuration: kept as a build switch for A/B runs only.
+#ifndef RTX_WIDE_WALK
+#define RTX_WIDE_WALK 0
+#endif
+constexpr uint32_t kMaxCut = RTX_MAX_CUT;    // <= 64: one wavefront holds the whole frontier of the cut's descent
+constexpr uint32_t kTileCutShift = 8u;       // TileDesc::flags
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);
 constexpr uint32_t kCostBuckets = 64u;
 constexpr uint32_t kStreamCtrWords = 4u;   // counters of the streamed (ablation) pipeline

@@ -189,7 +189,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long *__restrict__ 
 __host__ __device__ inline uint32_t lds_res_stride(uint32_t batch) { return batch | 1u; }   // odd: conflict-free column reads
 __host__ __device__ inline uint32_t lds_floats(uint32_t batch)
 {
-    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u;
+    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u + 2u * kMaxCut;
 }
 
 
@@ -287,23 +287,232 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
     return k < kCostBuckets ? k : kCostBuckets - 1u;
 }
 
+// what a chunk costs before it fetches its first record (ray set-up, the global triangles, its share of the ordered sum),
+// in units of one fetched record: the weight of a tile whose cut is empty
+constexpr uint32_t kChunkFixedCost = 8u;
+
+// scenes of more stream records than this do not cut per tile (probe_kernel)
+constexpr uint32_t kCutMaxNodes = 1u << 16;
+
 // independent wavefronts (tiles) per workgroup of probe_kernel: 1, 4 and 8 measured the same (m_ab_probewaves.log)
 #ifndef RTX_PROBE_WAVES
 #define RTX_PROBE_WAVES 1
 #endif
 
-// (Requesting the next stream record before the current one is tested — the next one visited unless an inner node
-//  fails — did not shorten this kernel: 0.1446 against 0.1416 ms for the scheduling pass of C3, same box, interleaved.)
-// primary walks of at least this many records are their tile's cost estimate themselves (0: always probe) — in scenes
-// of at most kProbeSkipMaxNodes stream records.  There the tiles that look into the mesh are few and their two walks
-// are the pass's critical path (C3: 0.143 -> 0.110 ms); in a large scene every mesh tile's primary walk is long, the
-// pass is bound by throughput, and the probing walk's better estimate is worth more than its time (C5, 1M triangles:
-// 68.5 ms with it, 70.9 without; profiles/r01/s_ab_misc.log).
-#ifndef RTX_PROBE_SKIP_VISITS
-#define RTX_PROBE_SKIP_VISITS 64
-#endif
-constexpr uint32_t kProbeSkipVisits = RTX_PROBE_SKIP_VISITS;
-constexpr uint32_t kProbeSkipMaxNodes = 1u << 16;
+// ---- the cut of a tile ------------------------------------------------------------------------------------------
+// The hundred chunks of a tile send their shadow rays from its hit points to the same few light points: all of them
+// lie in the SHAFT between O, the bounding box of the tile's hit points, and L, the bounding box of the light points
+// — the convex hull of O and L, which for axis-aligned boxes is the union over s in [0, 1] of the boxes whose bounds
+// run linearly from O's to L's ((1-s) O + s L, a Minkowski combination of boxes, is the box with the interpolated
+// bounds).  A node's box B meets the shaft iff some s satisfies six inequalities that are linear in s:
+//     B.lo_a <= O.hi_a + s (L.hi_a - O.hi_a)        B.hi_a >= O.lo_a + s (L.lo_a - O.lo_a)        a = x, y, z
+// — one division each, the same shape as a ray's slab test.  probe_kernel descends the tree ONCE per tile with this
+// test, breadth first, one node per work-item, and leaves the CUT in HBM: the subtrees (leaves, mostly) whose boxes
+// meet the shaft.  shade_tiles_kernel's chunks then walk these and nothing else (rtx_traverse.hpp: walk_cut): the
+// upper levels of the tree are descended once per tile instead of once per chunk, and the tiles whose shaft meets no
+// leaf — most of the open ground — do not walk at all.
+//
+// Soundness: culling only has to keep a superset.  A ray of the tile runs from a hit point p in O towards a light
+// point l in L; a candidate that can occlude it lies at a distance of at most the light's (main.rs:219-231, any-hit:
+// rtx_traverse.hpp), i.e. on the segment p..l, which the hull contains.  What the hull is compared with are the
+// reference's FLOATING-POINT box tests on a direction that is itself rounded: a box the reference accepts is met by
+// the true segment within a few units in the last place of the scene's largest coordinate M (the quotients of
+// bounding_box.rs:120-157 carry two roundings each, the unit direction three: below 2^-20 M in position units
+// together).  The test therefore takes every box DELTA = 2^-16 M larger on every side
+// (PreparedScene::shaft_delta; the stream's boxes are already 2^-19 M larger, cull_delta) and lets s run over
+// [-2^-8, 1 + 2^-8]; the same margin covers its own roundings (one reciprocal, one fused multiply-add per plane:
+// 2^-22 M in position units).  An inequality whose slope is zero or tiny is dropped, which only enlarges the
+// superset.  Nothing here decides a pixel: the rays still test every box and triangle of the cut themselves.
+struct Shaft {
+    float inv[6], off[6];     // q_c = plane_c * inv[c] + off[c]: the s at which constraint c becomes tight
+    uint32_t lower, upper;    // bit c: q_c is a lower / an upper bound of s (neither: the constraint is dropped)
+};
+constexpr float kShaftS0 = -0x1p-8f, kShaftS1 = 1.0f + 0x1p-8f;
+
+// constraint c = 2a (lower plane of B on axis a against the upper bound of the interpolated box) or 2a+1 (upper plane
+// against its lower bound); o = O's corner, g = L's corner - O's corner on that side
+__device__ __forceinline__ void shaft_constraint(Shaft &sh, uint32_t c, float o, float g, float delta)
+{
+    // c even:  B.lo - delta - o <= s g      g > 0: s >= q (lower bound)    g < 0: s <= q (upper bound)
+    // c odd:   B.hi + delta - o >= s g      g > 0: s <= q (upper bound)    g < 0: s >= q (lower bound)
+    const bool usable = fabsf(g) >= 0x1p-40f && fabsf(g) <= 0x1p60f;      // else dropped (conservative)
+    const float inv = __builtin_amdgcn_rcpf(g);
+    sh.inv[c] = usable ? inv : 0.0f;
+    sh.off[c] = usable ? (((c & 1u) ? delta : -delta) - o) * inv : 0.0f;
+    const bool positive = g > 0.0f;
+    const bool is_lower = usable && (((c & 1u) == 0u) == positive);
+    if (is_lower) sh.lower |= 1u << c;
+    if (usable && !is_lower) sh.upper |= 1u << c;
+}
+
+__device__ __forceinline__ bool shaft_meets(const Shaft &sh, const NodeDev &b)
+{
+    const float plane[6] = {b.lox, b.hix, b.loy, b.hiy, b.loz, b.hiz};
+    float s_lo = kShaftS0, s_hi = kShaftS1;
+#pragma unroll
+    for (uint32_t c = 0; c < 6u; ++c) {
+        const float q = __builtin_fmaf(plane[c], sh.inv[c], sh.off[c]);
+        s_lo = fmaxf(s_lo, (sh.lower >> c) & 1u ? q : kShaftS0);
+        s_hi = fminf(s_hi, (sh.upper >> c) & 1u ? q : kShaftS1);
+    }
+    return !(s_lo > s_hi);   // a NaN can only accept
+}
+
+// wave-wide minimum / maximum over the lanes (every lane gets the result)
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+// a value every lane holds, moved to a scalar register (the builtin is typed int: the bits go through, not the value)
+__device__ __forceinline__ float uniform(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Breadth-first descent of the wide tree with the shaft test, one frontier node per work-item; the frontier of a level
+// lives in registers (lane l holds its l-th node), the next one is gathered through 64 words of LDS.  A frontier
+// node's four child boxes are tested against the shaft.  A node with a LEAF child that meets the shaft becomes an
+// entry of the cut itself (the rays test the leaf's box when they walk that node — a leaf has no record of its own);
+// otherwise its inner children that meet the shaft form the next frontier, and a node none of whose children meets the
+// shaft is dropped.  Invariant: entries written + frontier nodes <= kMaxCut, so a level is one pass of the wavefront;
+// when the next level would break it, the frontier's live nodes become entries as they are and the descent stops.
+// Returns the number of entries written to `out` (byte offsets of wide nodes); *weight = a proxy of what one chunk's
+// walk of the cut will fetch.
+__device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ wide, const Shaft &sh,
+                                                   uint2 *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
+                                                   uint32_t &weight)
+{
+    uint32_t my = 0u, my_size = 0u, n_front = 1u, n_out = 0u, w = 0u;
+    for (;;) {
+        const bool have = lane < n_front;
+        bool meets[4] = {false, false, false, false}, leaf[4] = {false, false, false, false};
+        uint32_t ref[4] = {0u, 0u, 0u, 0u}, aux[4] = {0u, 0u, 0u, 0u};
+        if (have) {
+            const WideNode *nd = reinterpret_cast<const WideNode *>(reinterpret_cast<const char *>(wide) + my);
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) {
+                NodeDev bx;
+                bx.lox = nd->box[c][0]; bx.loy = nd->box[c][1]; bx.loz = nd->box[c][2];
+                bx.hix = nd->box[c][3]; bx.hiy = nd->box[c][4]; bx.hiz = nd->box[c][5];
+                ref[c] = nd->ref[c];
+                aux[c] = nd->aux[c];
+                leaf[c] = (ref[c] >> 31) != 0u;
+                meets[c] = !(leaf[c] && aux[c] == 0u) && shaft_meets(sh, bx);   // an empty slot never does
+            }
+        }
+        const bool with_leaf = (meets[0] && leaf[0]) || (meets[1] && leaf[1]) || (meets[2] && leaf[2]) || (meets[3] && leaf[3]);
+        const bool live = meets[0] || meets[1] || meets[2] || meets[3];
+        const bool expand = live && !with_leaf;
+        const uint32_t kids = expand ? (uint32_t)meets[0] + (uint32_t)meets[1] + (uint32_t)meets[2] + (uint32_t)meets[3] : 0u;
+        const unsigned long long m_live = ballot(live), m_entry = ballot(with_leaf);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // exclusive prefix of `kids` over the lanes, and its total
+        uint32_t before = 0u, total = 0u;
+#pragma unroll
+        for (uint32_t k = 1; k <= 4u; ++k) {
+            const unsigned long long mk = ballot(kids >= k);
+            before += (uint32_t)__popcll(mk & below);
+            total += (uint32_t)__popcll(mk);
+        }
+        const uint32_t n_entry = (uint32_t)__popcll(m_entry);
+        if (n_out + n_entry + total > kMaxCut) {      // stop here: the live nodes of this level are the rest of the cut
+            if (live) {
+                out[n_out + (uint32_t)__popcll(m_live & below)] = make_uint2(my, 0u);
+                w += 4u + 6u * (32u - (uint32_t)__clz((int)my_size));
+            }
+            n_out += (uint32_t)__popcll(m_live);
+            break;
+        }
+        if (with_leaf) {
+            out[n_out + (uint32_t)__popcll(m_entry & below)] = make_uint2(my, 0u);
+            w += 4u + 6u * (32u - (uint32_t)__clz((int)my_size));
+        }
+        n_out += n_entry;
+        if (total == 0u) break;
+        if (expand) {
+            uint32_t slot = before;
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c)
+                if (meets[c]) {
+                    l_front[slot] = ref[c];
+                    l_front[64u + slot] = aux[c];
+                    ++slot;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        n_front = total;
+        my = l_front[lane];
+        my_size = l_front[64u + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    weight = wave_sum(w);
+    return n_out;
+}
+
+// The same descent over the binary stream (what librtx.so ships; the wide form above is kept for A/B, DESIGN.md section
+// 4): one stream record per work-item, its own box against the shaft; a leaf that meets it becomes an entry, an inner
+// node's two children (the next record, and the one its `info` names) join the next frontier.  Entries are record
+// ranges [begin, end) of the stream.
+__device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__ nodes, uint32_t root, const Shaft &sh,
+                                                     uint2 *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
+                                                     uint32_t &weight)
+{
+    uint32_t my = root, n_front = 1u, n_out = 0u, w = 0u;
+    for (;;) {
+        const bool have = lane < n_front;
+        NodeDev nd = {};
+        if (have) nd = nodes[my];
+        const bool leaf = (nd.info >> 31) != 0u;
+        const bool pass = have && shaft_meets(sh, nd);
+        const unsigned long long m_pass = ballot(pass), m_exp = ballot(pass && !leaf), m_leaf = m_pass & ~m_exp;
+        const uint32_t n_pass = (uint32_t)__popcll(m_pass), n_exp = (uint32_t)__popcll(m_exp), n_leaf = n_pass - n_exp;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (n_out + n_leaf + 2u * n_exp > kMaxCut) {      // stop here: the passing nodes of this level are the rest of the cut
+            if (pass) {
+                out[n_out + (uint32_t)__popcll(m_pass & below)] = make_uint2(my, leaf ? my + 1u : nd.link);
+                const uint32_t size = leaf ? 1u : nd.link - my;
+                w += leaf ? 1u + 3u * nd.link : 4u + 6u * (31u - (uint32_t)__clz((int)size));
+            }
+            n_out += n_pass;
+            break;
+        }
+        if (pass && leaf) {
+            out[n_out + (uint32_t)__popcll(m_leaf & below)] = make_uint2(my, my + 1u);
+            w += 1u + 3u * nd.link;            // its box test and its primitive records
+        }
+        n_out += n_leaf;
+        if (n_exp == 0u) break;
+        if (pass && !leaf) {                    // children of the expanding node of rank k go to slots 2k, 2k+1
+            const uint32_t k = (uint32_t)__popcll(m_exp & below);
+            l_front[2u * k] = my + 1u;
+            l_front[2u * k + 1u] = nd.info;     // inner node: index of its second child (scene_prep.cpp)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        n_front = 2u * n_exp;
+        my = l_front[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    weight = wave_sum(w);
+    return n_out;
+}
 
 template <bool COUNT, bool FAST, bool SPHERES>
 __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
@@ -312,9 +521,12 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 {
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no LDS, no barrier)
+    // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no barrier; LDS only inside shaft_cut)
+    __shared__ uint32_t l_front_all[RTX_PROBE_WAVES][128];   // the cut's next frontier: node, subtree size
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile_id = blockIdx.x * RTX_PROBE_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *const l_front = l_front_all[wave_in_group];
+    const uint32_t tile_id = blockIdx.x * RTX_PROBE_WAVES + wave_in_group;
     if (tile_id >= n_tiles) return;
     uint32_t px, py, ly;
     const bool in_frame = tile_pixel(S, ts, tile_id % tiles_x, tile_id / tiles_x, lane, px, py, ly);
@@ -322,8 +534,13 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     float dx, dy, dz;
     primary_ray(S, in_frame, px, py, r, dx, dy, dz);
     LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
-    // (counted in every build: the walk's length is the cost estimate of a tile that looks into the mesh, below)
-    const bool ok = closest_hit<COUNT || kProbeSkipVisits != 0u, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
+#if RTX_WIDE_WALK
+    const bool ok = hit_wide<COUNT, FAST, SPHERES, false>((const WideNode RTX_CONSTANT *)S.wide, S.n_wide, tris, S.shade, nullptr, 0u, pr, wc,
+                                                          S.n_global, false);                                  // main.rs:187
+    (void)nodes;
+#else
+    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
+#endif
     const bool hit = ok && in_frame && pr.best_idx != kNone;
     const unsigned long long hit_mask = ballot(hit);
     const uint32_t n_hit = (uint32_t)__popcll(hit_mask);
@@ -359,24 +576,52 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         W.hits[(size_t)tile_id * 64u + slot] = h;
     }
     W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;
-    // cost probe: the walk of light sample 0 for the tile's hit pixels (its result is not used, only its length)
+    // The tile's cut (shaft_cut above) and, from it, the tile's cost estimate: chunks x (a chunk's fixed work + what a
+    // walk of the cut fetches).
     unsigned long long cost = 0;
+    uint32_t n_cut = 0u;
     const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
-    const unsigned long long primary_walk = wc.node_visits + wc.tri_visits;
-    if (kProbeSkipVisits != 0u && S.n_nodes <= kProbeSkipMaxNodes && primary_walk >= kProbeSkipVisits && n_hit != 0u && !(flags & 2u)) {
-        // A long primary walk: the tile looks into the mesh, and the shadow rays of what it sees start inside the
-        // mesh's boxes — their walks are long too.  The primary walk's own length stands in for the probing walk,
-        // which for these tiles would be the second half of the scheduling pass's critical path.
-        cost = (primary_walk + 1ull) * n_chunks;
-    } else if (n_hit != 0u && S.nb_light != 0u && !(flags & 2u)) {
-        const float *lp = S.light_points + 3u * (r * S.nb_light);
-        const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;
-        const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);
-        LaneRay sr = make_ray(hit, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);
-        sr.limit = dist_light;
-        WaveCounters probe;
-        (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
-        cost = (probe.node_visits + probe.tri_visits + 1ull) * n_chunks;
+    if (n_hit != 0u && S.nb_light != 0u && !(flags & 2u)) {
+        const float inf = __builtin_inff();
+        const float olx = uniform(wave_min(hit ? hx : inf)), ohx = uniform(wave_max(hit ? hx : -inf));
+        const float oly = uniform(wave_min(hit ? hy : inf)), ohy = uniform(wave_max(hit ? hy : -inf));
+        const float olz = uniform(wave_min(hit ? hz : inf)), ohz = uniform(wave_max(hit ? hz : -inf));
+        const float *lb = S.light_boxes + 6u * r;
+        Shaft sh;
+        sh.lower = 0u; sh.upper = 0u;
+        shaft_constraint(sh, 0u, ohx, lb[3] - ohx, S.shaft_delta);
+        shaft_constraint(sh, 1u, olx, lb[0] - olx, S.shaft_delta);
+        shaft_constraint(sh, 2u, ohy, lb[4] - ohy, S.shaft_delta);
+        shaft_constraint(sh, 3u, oly, lb[1] - oly, S.shaft_delta);
+        shaft_constraint(sh, 4u, ohz, lb[5] - ohz, S.shaft_delta);
+        shaft_constraint(sh, 5u, olz, lb[2] - olz, S.shaft_delta);
+        uint32_t weight = 0u;
+#if RTX_WIDE_WALK
+        if (S.n_wide != 0u)
+            n_cut = shaft_cut_wide(S.wide, sh, W.cut + (size_t)tile_id * kMaxCut, l_front, lane, weight);
+#else
+        // the tree proper: behind the root and the global triangles' leaf when there are any (scene_prep.cpp)
+        const uint32_t root = S.n_global != 0u ? 2u : 0u;
+        if (root < S.n_nodes && S.n_nodes <= kCutMaxNodes) {
+            n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut, l_front, lane, weight);
+        } else if (root < S.n_nodes) {
+            // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
+            // cut of sixteen subtrees prunes nothing, and what orders such a frame well is the length of a real walk — the
+            // tile's hit pixels towards light sample 0, its result unused.  The cut is the whole tree.  (Measured on the
+            // 1M-triangle soup: 61 ms with this estimate, 65-67 ms with the cut's proxy at any cut size.)
+            if (lane == 0) W.cut[(size_t)tile_id * kMaxCut] = make_uint2(root, S.n_nodes);
+            n_cut = 1u;
+            const float *lp = S.light_points + 3u * (r * S.nb_light);
+            const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;
+            const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);
+            LaneRay sr = make_ray(hit, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);
+            sr.limit = dist_light;
+            WaveCounters probe;
+            (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
+            weight = (uint32_t)(probe.node_visits + probe.tri_visits);
+        }
+#endif
+        cost = (unsigned long long)(kChunkFixedCost + weight) * n_chunks;
     }
     // A tile without a hit is finished here (main.rs:235: the sums stay as they are), a queued tile belongs to the
     // reference re-render: neither is scheduled for shade_tiles_kernel (cost class kNone).
@@ -394,7 +639,11 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     if (lane == 0) {
         const bool count_it = !(flags & 2u);
         const uint32_t key = (sky || (flags & 2u)) ? kNone : cost_class(cost);
-        W.tiles[tile_id] = TileDesc{key, n_hit, flags, counted + (count_it ? n_hit : 0u)};
+#if RTX_EXPERIMENT_TIMELINE
+        W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), 0u};   // spare word: the tile's jobs add their durations
+#else
+        W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), counted + (count_it ? n_hit : 0u)};
+#endif
         if (COUNT) {
             flush_counters<COUNT>(counters, count_it ? (unsigned long long)n_hit : 0ull, wc);
             if (counters) {   // the scheduling pass's share of the record fetches (the probing walk is not counted)
@@ -538,8 +787,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     const uint32_t res_stride = lds_res_stride(batch);
     float *const l_pix = l_res + 64u * res_stride;                                    // per pixel: running sums r,g,b + hit slot
     uint32_t *const l_ctl = reinterpret_cast<uint32_t *>(l_pix + 64u * 4u);           // [1] redo flag, [3] tile
+    uint32_t *const l_cut = l_ctl + 4u;                                                // the tile's cut: (begin, end) pairs
 
+#if RTX_WIDE_WALK
+    const WideNode RTX_CONSTANT *wide = (const WideNode RTX_CONSTANT *)S.wide;
+#else
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
+#endif
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
     // the first global triangle's plane, fetched once (rtx_traverse.hpp: plane_rules_out)
     const TriRec RTX_CONSTANT *planes = (const TriRec RTX_CONSTANT *)S.planes;
@@ -554,15 +808,28 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveCounters wc;
+#if !RTX_WIDE_WALK
+    const bool whole_tree = S.n_nodes > kCutMaxNodes;
+#endif
     const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
     static_assert(sizeof(HitRec) == kHitStride * sizeof(float), "the LDS hit record is the HBM hit record");
 
+#if RTX_EXPERIMENT_TIMELINE     // timing experiment only: a job's duration (100 MHz ticks, claim to next claim) is added to its
+    uint32_t tl_tile = kNone;   // tile's spare word by the work-item that claims the jobs
+    unsigned long long tl_t0 = 0;
+#endif
     for (;;) {
         if (threadIdx.x == 0) {
             // q-th job, costliest class first
             const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
             l_ctl[3] = q < W.buckets[0] ? W.buckets[3u * kCostBuckets + q] : kNone;
             l_ctl[1] = 0u;
+#if RTX_EXPERIMENT_TIMELINE
+            const unsigned long long now = wall_clock64();
+            if (tl_tile != kNone) atomicAdd(&W.tiles[tl_tile].pad, (uint32_t)(now - tl_t0));
+            tl_tile = l_ctl[3] == kNone ? kNone : (l_ctl[3] & kJobTileMask);
+            tl_t0 = now;
+#endif
         }
         __syncthreads();
         const uint32_t job = __builtin_amdgcn_readfirstlane(l_ctl[3]);
@@ -578,9 +845,12 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         const uint32_t tflags = __builtin_amdgcn_readfirstlane(td.flags);
         const bool sample_major = (tflags & 1u) != 0u;
         const bool skip = (tflags & 2u) != 0u;      // already queued for the reference re-render
+        const uint32_t n_cut = (tflags >> kTileCutShift) & 0xFFu;
         if (!skip) {
             const float *src = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u + h0);
             for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = src[k];
+            if (threadIdx.x < 2u * n_cut)
+                l_cut[threadIdx.x] = reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x];
             if (wave == 0) {
                 const size_t pix = (size_t)tile_id * 64u + lane;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                               // main.rs:182
@@ -625,14 +895,32 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         const bool no_ground = have_plane &&
                             (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
-                        const bool ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
+#if RTX_EXPERIMENT_NO_WALK      // timing experiment only (wrong pixels): what a frame costs without any walk
+                        const bool ok = true;
+                        (void)no_ground;
+#else
+#if RTX_WIDE_WALK
+                        const bool ok = hit_wide<COUNT, FAST, SPHERES, true>(wide, S.n_wide, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
+#else
+                        // main.rs:204.  Scenes too large for per-tile cuts (probe_kernel: kCutMaxNodes) walk the whole
+                        // stream: that loop is three scalar instructions per record shorter than the loop over a cut's
+                        // ranges, which is worth 9 % of a frame of the 1M-triangle soup
+                        const bool ok = whole_tree
+                            ? any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground)
+                            : any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);
+#endif
+#endif
                         if (!ok && lane == 0) l_ctl[1] = 1u;
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
                         else shadow_result(l_hit, l_res, res_stride, sr);
                     }
                     __syncthreads();
                     // phase 3: ordered accumulation, one work-item per pixel (wave 0)
+#if RTX_EXPERIMENT_NO_SUM       // timing experiment only (wrong pixels): what a frame costs without the ordered sums
+                    if (false) {
+#else
                     if (wave == 0) {
+#endif
                         const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
                         const bool hit = slot < 64u;
                         float acc_r = l_pix[4u * lane], acc_g = l_pix[4u * lane + 1u], acc_b = l_pix[4u * lane + 2u];
@@ -783,6 +1071,7 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);   // streamed (ablation) pipeline only; 16 B
     b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts) * sizeof(uint32_t) : 0u;
+    b.cut = probe ? tiles * kMaxCut * sizeof(uint2) : 0u;
     return b;
 }
 

@@ -683,31 +683,17 @@ __device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float
     return magnitude || away;
 }
 
-// The walk itself, for one kind of box test (USE_FAST: the multiply-based conservative test, else the exact one).
-// first_global: 1 when the first global triangle has been ruled out for every lane (plane_rules_out), else 0.
+// The walk itself over the records [i, end) of the stream, for one kind of box test (USE_FAST: the multiply-based
+// conservative test, else the exact one).  Returns the lanes still walking (any-hit walks: the others found their
+// occluder); a wavefront without such lanes leaves the range at once.
 template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST, bool LEAN = false>
-__device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
-                                            const TriRec RTX_CONSTANT *__restrict__ tris,
-                                            const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
-                                            unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
-                                            uint32_t n_global, uint32_t first_global = 0u)
+__device__ __forceinline__ unsigned long long walk_range(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                                         const TriRec RTX_CONSTANT *__restrict__ tris,
+                                                         const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
+                                                         LaneRay &r, unsigned long long alive,
+                                                         unsigned long long &n_active, WaveCounters &wc)
 {
-    // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
-    // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
-    // DESIGN.md) every enclosing box, the root's included.  One node in thirteen on the default scene.
-    uint32_t i = (RTX_SKIP_ROOT_TEST && n_nodes > 1u) ? 1u : 0u;
-    if (RTX_SKIP_ROOT_TEST && n_global != 0u) {
-        // the "global" triangles (scene_prep.cpp: as large as the scene, i.e. the ground) sit in the leaf at node 1:
-        // tested here without its box test, then the walk starts at the root of the tree proper
-        leaf_triangles<COUNT, ANYHIT, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
-        if (ANYHIT) {
-            alive = ballot(r.active);
-            if (alive == 0ull) return;
-            if (COUNT) n_active = __popcll(alive);
-        }
-        i = 2u;
-    }
-    while (i < n_nodes) {
+    while (i < end) {
 #if RTX_ASM_NODE_LOAD
         const NodeRec cur = load_node_at(nodes, i);
 #else
@@ -736,7 +722,7 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
             if (ANYHIT) {   // lanes that found an occluder have left the walk (r.active); so does a wavefront without lanes
                 alive = ballot(r.active);
 #if RTX_WALK_SINGLE_EXIT
-                if (alive == 0ull) i = n_nodes - 1u;   // the step below ends the walk: the loop keeps ONE exit test
+                if (alive == 0ull) i = end - 1u;        // the step below ends the walk: the loop keeps ONE exit test
 #else
                 if (alive == 0ull) break;
 #endif
@@ -757,6 +743,34 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
         i = onward ? i + 1u : cur.link;
 #endif
     }
+    return alive;
+}
+
+// The walk of the whole stream, for one kind of box test (USE_FAST: the multiply-based conservative test, else the exact one).
+// first_global: 1 when the first global triangle has been ruled out for every lane (plane_rules_out), else 0.
+template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST, bool LEAN = false>
+__device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                            const TriRec RTX_CONSTANT *__restrict__ tris,
+                                            const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
+                                            unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
+                                            uint32_t n_global, uint32_t first_global = 0u)
+{
+    // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
+    // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
+    // DESIGN.md) every enclosing box, the root's included.  One node in thirteen on the default scene.
+    uint32_t i = (RTX_SKIP_ROOT_TEST && n_nodes > 1u) ? 1u : 0u;
+    if (RTX_SKIP_ROOT_TEST && n_global != 0u) {
+        // the "global" triangles (scene_prep.cpp: as large as the scene, i.e. the ground) sit in the leaf at node 1:
+        // tested here without its box test, then the walk starts at the root of the tree proper
+        leaf_triangles<COUNT, ANYHIT, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
+        if (ANYHIT) {
+            alive = ballot(r.active);
+            if (alive == 0ull) return;
+            if (COUNT) n_active = __popcll(alive);
+        }
+        i = 2u;
+    }
+    (void)walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, i, n_nodes, r, alive, n_active, wc);
 }
 
 // SPHERES = false compiles the Sphere arm out: scenes without spheres (every BASELINE configuration) run the
@@ -797,6 +811,201 @@ __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__
                                         bool first_global_ruled_out = false)
 {
     return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
+}
+
+// ---- the wide walk ---------------------------------------------------------------------------------------------------
+// What the kernels run: the same tree with FOUR children per node (scene_prep.h: WideNode).  A step fetches one
+// 128-byte node with two scalar loads, tests its four child boxes in one stretch of vector code, votes once per child
+// and then handles the children whose vote is not empty: a leaf child's primitives are tested on the spot, an inner
+// child goes onto the wave's stack — the 64 lanes of ONE vector register, written and read by lane number, so a push
+// and a pop are two instructions and touch no memory.  The reference never prunes by distance, so the order of the
+// visits is free; what matters is the cost of the step's scalar skeleton (the scalar unit serves the whole compute unit,
+// four wavefronts' vector units wait on it): the binary walk paid about fifteen scalar instructions per BOX — its
+// fetch, wait, votes, leaf test and successor select — this one pays them per FOUR boxes, and a walk is a third as many
+// dependent steps long.  Same candidate set: every child box is the box of a node of the binary tree, i.e. a box that
+// contains the exact boxes of the leaves below it.
+__device__ __forceinline__ void load_wide_at(const WideNode RTX_CONSTANT *base, uint32_t byte_offset, u32x16 &a, u32x16 &b)
+{
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %3 offset:0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(base), "s"(byte_offset));
+}
+
+// lanes whose ray may pass the (moved-out, see box_mask) box: ONE vote — entry, not before the origin, <= exit
+template <bool USE_FAST>
+__device__ __forceinline__ unsigned long long wide_child_mask(uint32_t ulox, uint32_t uloy, uint32_t uloz, uint32_t uhix,
+                                                              uint32_t uhiy, uint32_t uhiz, const LaneRay &r)
+{
+    const float lox = __uint_as_float(ulox), loy = __uint_as_float(uloy), loz = __uint_as_float(uloz);
+    const float hix = __uint_as_float(uhix), hiy = __uint_as_float(uhiy), hiz = __uint_as_float(uhiz);
+    if (USE_FAST) {
+        const float ax = __builtin_fmaf(lox, r.ix, r.nx), bx = __builtin_fmaf(hix, r.ix, r.nx);
+        const float ay = __builtin_fmaf(loy, r.iy, r.ny), by = __builtin_fmaf(hiy, r.iy, r.ny);
+        const float az = __builtin_fmaf(loz, r.iz, r.nz), bz = __builtin_fmaf(hiz, r.iz, r.nz);
+        const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        return ballot(!(fmaxf(t_in, 0.0f) > t_out));      // = !(t_in > t_out) && !(t_out < 0); a NaN can only accept
+    }
+    return ballot(slab_exact(lox, loy, loz, hix, hiy, hiz, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz));
+}
+
+// The walk below the wide node at byte offset `entry`; returns the lanes still walking (see walk_range).
+// A step: pop a wide node, fetch it, test its four boxes, then sort the children whose vote is not empty by kind —
+// inner children are pushed (by predication, no branch: a push is a select on the lane number), leaf children are
+// queued in four scalar registers and their primitives tested right away, in ONE loop with one call site.  An any-hit
+// walk whose lanes have all found their occluder empties stack and queue instead of leaving the loops.  Everything that
+// steers the loops is a 0/1 integer in a scalar register (cf. walk_range).
+template <bool COUNT, bool SPHERES, bool ANYHIT, bool USE_FAST>
+__device__ __forceinline__ unsigned long long walk_wide(const WideNode RTX_CONSTANT *__restrict__ wide,
+                                                        const TriRec RTX_CONSTANT *__restrict__ tris,
+                                                        const ShadeRec *__restrict__ shade, uint32_t entry, LaneRay &r,
+                                                        unsigned long long alive, unsigned long long &n_active,
+                                                        WaveCounters &wc)
+{
+    const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t stack = entry;   // lane k: byte offset of the k-th pending wide node; lane 0 = entry
+    uint32_t sp = 1u;         // wave-uniform
+    do {
+        --sp;
+        const uint32_t x = __builtin_amdgcn_readlane(stack, sp);
+        u32x16 a, b;
+        load_wide_at(wide, x, a, b);
+        const unsigned long long m0 = wide_child_mask<USE_FAST>(a[0], a[1], a[2], a[3], a[4], a[5], r);
+        const unsigned long long m1 = wide_child_mask<USE_FAST>(a[6], a[7], a[8], a[9], a[10], a[11], r);
+        const unsigned long long m2 = wide_child_mask<USE_FAST>(a[12], a[13], a[14], a[15], b[0], b[1], r);
+        const unsigned long long m3 = wide_child_mask<USE_FAST>(b[2], b[3], b[4], b[5], b[6], b[7], r);
+        if (COUNT) { wc.box_tests += 4ull * n_active; wc.node_visits += 1; }
+        // p = a walking lane passes the child's box; leaf children go to the queue (q0 first), inner ones to the stack
+        uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u, nq = 0u;
+#define RTX_WIDE_SORT(mask, ref)                                                                                          \
+        {                                                                                                                \
+            uint32_t p;                                                                                                  \
+            asm("s_and_b64 vcc, %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(p) : "s"(mask), "s"(alive) : "vcc", "scc");       \
+            const uint32_t is_leaf = (ref) >> 31, pl = p & is_leaf, pi = p & ~is_leaf;                                   \
+            const uint32_t slot = pi ? sp : 64u;                                                                         \
+            stack = lane_id == slot ? (ref) : stack;                                                                     \
+            sp += pi;                                                                                                    \
+            q3 = pl ? q2 : q3; q2 = pl ? q1 : q2; q1 = pl ? q0 : q1; q0 = pl ? (ref) : q0;                               \
+            nq += pl;                                                                                                    \
+        }
+        RTX_WIDE_SORT(m0, b[8])
+        RTX_WIDE_SORT(m1, b[9])
+        RTX_WIDE_SORT(m2, b[10])
+        RTX_WIDE_SORT(m3, b[11])
+#undef RTX_WIDE_SORT
+        while (nq != 0u) {
+            const uint32_t leaf = q0;
+            q0 = q1; q1 = q2; q2 = q3;
+            --nq;
+            const uint32_t first = leaf & kWideLeafFirstMask, count = (leaf >> kWideLeafCountShift) & 31u;
+            if (SPHERES && (leaf & kSphereFlag))
+                leaf_spheres<COUNT, ANYHIT>(tris, shade, first, count, r, n_active, wc);
+            else
+                leaf_triangles<COUNT, ANYHIT, USE_FAST>(tris, shade, first, count, r, alive, n_active, wc);
+            if (ANYHIT) {   // lanes that found an occluder have left the walk; so does a wavefront without lanes
+                alive = ballot(r.active);
+                if (alive == 0ull) { sp = 0u; nq = 0u; }
+                if (COUNT) n_active = __popcll(alive);
+            }
+        }
+    } while (sp != 0u);
+    return alive;
+}
+
+// One closest-hit (ANYHIT: any-hit) traversal of the wide tree; the rules of closest_hit above apply (false and no
+// trace when an active lane's direction is hard; the exact box test when one is soft).  cut: NULL = the whole tree,
+// else LDS words, n_cut pairs whose first word is the byte offset of a wide node the walk starts from (shaft_cut_wide).
+template <bool COUNT, bool FAST, bool SPHERES, bool ANYHIT>
+__device__ __forceinline__ bool hit_wide(const WideNode RTX_CONSTANT *__restrict__ wide, uint32_t n_wide,
+                                         const TriRec RTX_CONSTANT *__restrict__ tris,
+                                         const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
+                                         uint32_t n_cut, LaneRay &r, WaveCounters &wc, uint32_t n_global,
+                                         bool first_global_ruled_out)
+{
+    unsigned long long alive = ballot(r.active);
+    const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
+                                       ballot(fabsf(r.dy) >= 0x1p-60f) & ballot(fabsf(r.dy) <= 2.0f) &
+                                       ballot(fabsf(r.dz) >= 0x1p-60f) & ballot(fabsf(r.dz) <= 2.0f);
+    const bool all_regular = (alive & ~regular) == 0ull;          // direction classes: see closest_hit
+    if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
+    unsigned long long n_active = 0;
+    if (COUNT) n_active = __popcll(alive);
+    const bool use_fast = FAST && all_regular;
+    if (n_global != 0u) {   // the global triangles (the ground): every walk tests them, without a box test
+        const uint32_t first = (use_fast && first_global_ruled_out) ? 1u : 0u;
+        if (use_fast) leaf_triangles<COUNT, ANYHIT, true>(tris, shade, first, n_global - first, r, alive, n_active, wc);
+        else leaf_triangles<COUNT, ANYHIT, false>(tris, shade, first, n_global - first, r, alive, n_active, wc);
+        if (ANYHIT) {
+            alive = ballot(r.active);
+            if (alive == 0ull) return true;
+            if (COUNT) n_active = __popcll(alive);
+        }
+    }
+    if (n_wide == 0u) return true;
+    if (cut == nullptr) {
+        if (use_fast) (void)walk_wide<COUNT, SPHERES, ANYHIT, true>(wide, tris, shade, 0u, r, alive, n_active, wc);
+        else (void)walk_wide<COUNT, SPHERES, ANYHIT, false>(wide, tris, shade, 0u, r, alive, n_active, wc);
+        return true;
+    }
+    for (uint32_t k = 0; k < n_cut; ++k) {
+        const uint32_t entry = __builtin_amdgcn_readfirstlane(cut[2u * k]);
+        if (use_fast) alive = walk_wide<COUNT, SPHERES, ANYHIT, true>(wide, tris, shade, entry, r, alive, n_active, wc);
+        else alive = walk_wide<COUNT, SPHERES, ANYHIT, false>(wide, tris, shade, entry, r, alive, n_active, wc);
+        if (ANYHIT && alive == 0ull) break;
+    }
+    return true;
+}
+
+// The shadow walk of a chunk whose tile carries a CUT of the tree (rtx_kernel.hip: shaft_cut): the subtrees — record
+// ranges [begin, end) of the stream, at most kMaxCut of them — that the tile's shaft towards the light can touch.
+// Every box a ray of the tile passes lies in one of them (or holds one), so walking the ranges one after another
+// visits a superset of the candidates the whole-stream walk would find among the occluders, and an any-hit result does
+// not depend on the order.  The upper levels of the tree, which the hundred chunks of a tile would otherwise descend a
+// hundred times, are walked once per tile.  cut: LDS, (begin, end) pairs.
+template <bool COUNT, bool SPHERES, bool USE_FAST, bool LEAN>
+__device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                         const TriRec RTX_CONSTANT *__restrict__ tris,
+                                         const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
+                                         uint32_t n_cut, LaneRay &r, unsigned long long alive,
+                                         unsigned long long n_active, WaveCounters &wc, uint32_t n_global,
+                                         uint32_t first_global)
+{
+    if (n_global != 0u) {   // the global triangles (the ground): every walk tests them, without a box test
+        leaf_triangles<COUNT, true, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
+        alive = ballot(r.active);
+        if (alive == 0ull) return;
+        if (COUNT) n_active = __popcll(alive);
+    }
+    // (One loop over all ranges — refilling [i, end) inside walk_range's loop — was measured too: the loop's two-way
+    //  exit costs five scalar instructions per record there, this nesting three, the whole-stream walk none.)
+    for (uint32_t k = 0; k < n_cut; ++k) {
+        const uint32_t begin = __builtin_amdgcn_readfirstlane(cut[2u * k]);
+        const uint32_t end = __builtin_amdgcn_readfirstlane(cut[2u * k + 1u]);
+        alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin, end, r, alive, n_active, wc);
+        if (alive == 0ull) break;
+    }
+}
+
+template <bool COUNT, bool FAST, bool SPHERES = false, bool LEAN = false>
+__device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                            const TriRec RTX_CONSTANT *__restrict__ tris,
+                                            const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
+                                            uint32_t n_cut, LaneRay &r, WaveCounters &wc, uint32_t n_global,
+                                            bool first_global_ruled_out)
+{
+    const unsigned long long alive = ballot(r.active);
+    const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
+                                       ballot(fabsf(r.dy) >= 0x1p-60f) & ballot(fabsf(r.dy) <= 2.0f) &
+                                       ballot(fabsf(r.dz) >= 0x1p-60f) & ballot(fabsf(r.dz) <= 2.0f);
+    const bool all_regular = (alive & ~regular) == 0ull;          // direction classes: see closest_hit
+    if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
+    unsigned long long n_active = 0;
+    if (COUNT) n_active = __popcll(alive);
+    if (FAST && all_regular)
+        walk_cut<COUNT, SPHERES, true, LEAN>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global,
+                                             (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
+    else
+        walk_cut<COUNT, SPHERES, false, false>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global, 0u);
+    return true;
 }
 
 }  // namespace

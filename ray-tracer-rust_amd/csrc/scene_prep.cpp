@@ -286,8 +286,11 @@ struct Box {
 
 class TreeBuilder {
 public:
-    TreeBuilder(std::vector<Prim> &prims, std::vector<NodeRec> &nodes, uint32_t leaf_max, double box_cost)
-        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost) {}
+    // depth_cap: levels the tree may have.  A range that could not be finished within the cap by halving is halved
+    // from there on (median split along its widest centroid axis) instead of split by the SAH.
+    TreeBuilder(std::vector<Prim> &prims, std::vector<NodeRec> &nodes, uint32_t leaf_max, double box_cost,
+                uint32_t depth_cap = 64u)
+        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost), depth_cap_(depth_cap) {}
 
     uint32_t leaves = 0, max_leaf = 0, depth = 0;
 
@@ -311,7 +314,21 @@ public:
         nodes_.push_back(rec);
 
         uint32_t mid = 0;
-        bool split = count > 1 && choose_split(begin, end, bounds, cbounds, mid);
+        uint32_t halvings = 0;                   // ceil(log2(count)): levels a balanced subtree over this range needs below here
+        while ((1ull << halvings) < count) ++halvings;
+        const bool balanced = level + 1u + halvings + 1u >= depth_cap_;
+        bool split = false;
+        if (balanced && count > 1) {
+            int axis = 0;
+            for (int k = 1; k < 3; ++k)
+                if (cbounds.hi[k] - cbounds.lo[k] > cbounds.hi[axis] - cbounds.lo[axis]) axis = k;
+            mid = begin + count / 2;
+            std::nth_element(prims_.begin() + begin, prims_.begin() + mid, prims_.begin() + end,
+                             [axis](const Prim &a, const Prim &b) { return a.c[axis] < b.c[axis]; });
+            split = count > leaf_max_;
+        } else {
+            split = count > 1 && choose_split(begin, end, bounds, cbounds, mid);
+        }
         if (!split && count > leaf_max_) {        // coincident centroids: split by position in the list
             mid = begin + count / 2;
             split = true;
@@ -398,9 +415,137 @@ private:
     std::vector<NodeRec> &nodes_;
     uint32_t leaf_max_;
     double box_cost_;
+    uint32_t depth_cap_;
 };
 
 }  // namespace
+
+// The binary tree with grandchildren pulled up: starting from a node's two children, the inner child with the largest
+// box is replaced by its own two children until four slots are used or only leaves remain.  Visiting order is free
+// (the reference never prunes by distance), so the slots keep the order in which they were filled.  A leaf of more
+// than kWideLeafMax records (RTX_ACCEL_BRUTE, a large leaf_max) becomes a subtree of its own over runs of its records.
+uint32_t wide_nodes_build(const std::vector<NodeRec> &nodes, uint32_t root, const float *prim_boxes, std::vector<WideNode> &out)
+{
+    out.clear();
+    if (root >= nodes.size()) return 0;
+    // a child to be: a node of the binary tree, or a run [first, first + count) of a large leaf's records
+    struct Kid {
+        bool run;
+        uint32_t bin;                // !run
+        uint32_t first, count, flags;// run (flags: kSphereFlag or 0)
+        float lo[3], hi[3];
+    };
+    auto kid_of_node = [&](uint32_t i) {
+        Kid k{};
+        const NodeRec &n = nodes[i];
+        std::memcpy(k.lo, n.bmin, 12);
+        std::memcpy(k.hi, n.bmax, 12);
+        if ((n.info & kLeafFlag) && n.link > kWideLeafMax) {
+            k.run = true; k.first = n.info & kLeafIndexMask; k.count = n.link; k.flags = n.info & kSphereFlag;
+        } else {
+            k.run = false; k.bin = i;
+        }
+        return k;
+    };
+    auto kid_of_run = [&](uint32_t first, uint32_t count, uint32_t flags) {
+        Kid k{};
+        k.run = true; k.first = first; k.count = count; k.flags = flags;
+        for (int a = 0; a < 3; ++a) { k.lo[a] = FLT_MAX; k.hi[a] = -FLT_MAX; }
+        for (uint32_t i = first; i < first + count; ++i)
+            for (int a = 0; a < 3; ++a) {
+                k.lo[a] = std::fmin(k.lo[a], prim_boxes[6 * static_cast<size_t>(i) + a]);
+                k.hi[a] = std::fmax(k.hi[a], prim_boxes[6 * static_cast<size_t>(i) + 3 + a]);
+            }
+        return k;
+    };
+    auto is_leaf = [&](const Kid &k) { return k.run ? k.count <= kWideLeafMax : (nodes[k.bin].info & kLeafFlag) != 0u; };
+    auto area = [&](const Kid &k) {
+        const double dx = double(k.hi[0]) - k.lo[0], dy = double(k.hi[1]) - k.lo[1], dz = double(k.hi[2]) - k.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    // the two children an inner kid splits into
+    auto split = [&](const Kid &k, Kid &x, Kid &y) {
+        if (k.run) {
+            const uint32_t half = ((k.count / 2u + kWideLeafMax - 1u) / kWideLeafMax) * kWideLeafMax;   // whole runs to the left
+            const uint32_t left = std::min(std::max(half, kWideLeafMax), k.count - 1u);
+            x = kid_of_run(k.first, left, k.flags);
+            y = kid_of_run(k.first + left, k.count - left, k.flags);
+        } else {
+            x = kid_of_node(k.bin + 1u);
+            y = kid_of_node(nodes[k.bin].info);
+        }
+    };
+    bool far_point = true;
+    for (int a = 0; a < 3; ++a)
+        far_point = far_point && std::fabs(nodes[root].bmin[a]) < 0x1p90f && std::fabs(nodes[root].bmax[a]) < 0x1p90f;
+    struct Todo { Kid kid; uint32_t wide, level; };
+    std::vector<Todo> todo;
+    uint32_t depth = 0;
+    out.emplace_back();
+    todo.push_back({kid_of_node(root), 0u, 1u});
+    while (!todo.empty()) {
+        const Todo t = todo.back();
+        todo.pop_back();
+        if (t.level > depth) depth = t.level;
+        Kid kids[4];
+        uint32_t n = 0;
+        if (is_leaf(t.kid)) {
+            kids[n++] = t.kid;                                   // only the root can be a leaf here
+        } else {
+            split(t.kid, kids[0], kids[1]);
+            n = 2;
+            while (n < 4u) {
+                int best = -1;
+                double best_area = -1.0;
+                for (uint32_t k = 0; k < n; ++k)
+                    if (!is_leaf(kids[k]) && area(kids[k]) > best_area) { best_area = area(kids[k]); best = int(k); }
+                if (best < 0) break;
+                const Kid b = kids[best];
+                split(b, kids[best], kids[n]);
+                ++n;
+            }
+        }
+        WideNode w;
+        for (uint32_t c = 0; c < 4u; ++c) {
+            if (c < n) {
+                const Kid &k = kids[c];
+                for (int a = 0; a < 3; ++a) { w.box[c][a] = k.lo[a]; w.box[c][3 + a] = k.hi[a]; }
+                if (is_leaf(k)) {
+                    const uint32_t first = k.run ? k.first : (nodes[k.bin].info & kLeafIndexMask);
+                    const uint32_t count = k.run ? k.count : nodes[k.bin].link;
+                    const uint32_t flags = k.run ? k.flags : (nodes[k.bin].info & kSphereFlag);
+                    w.ref[c] = kLeafFlag | flags | (count << kWideLeafCountShift) | first;
+                    w.aux[c] = count;
+                } else {
+                    const uint32_t child = static_cast<uint32_t>(out.size());
+                    out.emplace_back();
+                    w.ref[c] = child * static_cast<uint32_t>(sizeof(WideNode));
+                    w.aux[c] = 0;                                // filled in below
+                    todo.push_back({k, child, t.level + 1u});
+                }
+            } else {
+                // a leaf of no record.  Its box is a point far outside the scene, which no ray passes unless its three
+                // direction components are equal to the last bit — and then nothing is tested; in a scene that large
+                // itself, the first child's box (the slot then costs an empty turn of the leaf loop when that child passes)
+                if (far_point) for (int a = 0; a < 6; ++a) w.box[c][a] = 0x1p100f;
+                else std::memcpy(w.box[c], w.box[0], sizeof w.box[c]);
+                w.ref[c] = kLeafFlag;
+                w.aux[c] = 0;
+            }
+        }
+        out[t.wide] = w;
+    }
+    // subtree sizes: children were appended after their parent, so a reverse sweep sees them first
+    std::vector<uint32_t> size(out.size(), 1u);
+    for (size_t i = out.size(); i-- > 0;)
+        for (uint32_t c = 0; c < 4u; ++c)
+            if (!(out[i].ref[c] & kLeafFlag)) {
+                const uint32_t child = out[i].ref[c] / static_cast<uint32_t>(sizeof(WideNode));
+                out[i].aux[c] = size[child];
+                size[i] += size[child];
+            }
+    return depth;
+}
 
 int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
 {
@@ -442,6 +587,17 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                 light_sample(d.light_v0, d.light_v1, d.light_v2, d.samples[2 * k], d.samples[2 * k + 1],
                              &s.light_points[3 * (static_cast<size_t>(r) * d.nb_light_sample + i)]);
             }
+
+        // bounding box of the light points of primary ray r: one end of a tile's shaft (rtx_kernel.hip: shaft_cut)
+        s.light_boxes.assign(6 * static_cast<size_t>(d.nb_ray), 0.0f);
+        for (uint32_t r = 0; r < d.nb_ray; ++r) {
+            float *b = &s.light_boxes[6 * static_cast<size_t>(r)];
+            for (int k = 0; k < 3; ++k) { b[k] = std::numeric_limits<float>::infinity(); b[3 + k] = -b[k]; }
+            for (uint32_t i = 0; i < d.nb_light_sample; ++i) {
+                const float *p = &s.light_points[3 * (static_cast<size_t>(r) * d.nb_light_sample + i)];
+                for (int k = 0; k < 3; ++k) { b[k] = std::fmin(b[k], p[k]); b[3 + k] = std::fmax(b[3 + k], p[k]); }
+            }
+        }
 
         const int grc = build_gamma_thresholds(s.gamma_thr);
         if (grc != RTX_OK) return grc;
@@ -502,6 +658,11 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             for (int k = 0; k < 3; ++k) magnitude = std::fmax(magnitude, std::fabs(d.eye[k]));
             s.cull_delta = magnitude * 0x1p-19f + 0x1p-100f;
             if (!std::isfinite(s.cull_delta)) return RTX_ERR_UNSUPPORTED;
+            // PreparedScene::shaft_delta: the same with the light points counted in (a shaft ends on them)
+            for (float b : s.light_boxes)
+                if (std::isfinite(b)) magnitude = std::fmax(magnitude, std::fabs(b));
+            s.shaft_delta = magnitude * 0x1p-16f + 0x1p-100f;
+            if (!std::isfinite(s.shaft_delta)) return RTX_ERR_UNSUPPORTED;
         }
 
         // the reference's own tree (see ref_tree_build): ranks for exact ties, stream for hard directions
@@ -517,6 +678,24 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
         for (uint32_t i = 0; i < n_prims; ++i)
             s.shade[i].rank = d.tie_rank ? d.tie_rank[i] : (want_ref ? ref_rank[i] : i);
 
+        // after a tree is built: inner nodes of the library's stream name their second child in `info` (the first one
+        // is the next record; the binary walks only look at bit 31 of an inner node's info), and the tree proper (behind
+        // the root and the global triangles' leaf when there are any) is restated with four children per node — what
+        // the kernels walk
+        auto finish_tree = [&]() {
+            for (size_t i = 0; i < s.nodes.size(); ++i)
+                if (!(s.nodes[i].info & kLeafFlag)) {
+                    const NodeRec &first = s.nodes[i + 1];
+                    s.nodes[i].info = (first.info & kLeafFlag) ? static_cast<uint32_t>(i) + 2u : first.link;
+                }
+            const uint32_t proper = s.n_global != 0u ? 2u : 0u;
+            std::vector<float> order_boxes(6 * static_cast<size_t>(n_prims));     // primitive boxes in leaf order
+            for (uint32_t i = 0; i < n_prims; ++i) {
+                std::memcpy(&order_boxes[6 * static_cast<size_t>(i)], prims[i].lo, 12);
+                std::memcpy(&order_boxes[6 * static_cast<size_t>(i) + 3], prims[i].hi, 12);
+            }
+            s.wide_depth = wide_nodes_build(s.nodes, proper, order_boxes.data(), s.wide);
+        };
         s.nodes.clear();
         s.nodes.reserve(2 * static_cast<size_t>(n_prims));
         if (d.accel == RTX_ACCEL_BRUTE) {
@@ -555,6 +734,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             s.n_leaves = static_cast<uint32_t>(s.nodes.size() == 1 ? 1 : 2);
             s.max_leaf_tris = std::max(n_tri_prims, n_prims - n_tri_prims);
             s.depth = s.nodes.size() == 1 ? 1 : 2;
+            finish_tree();
         } else {
             uint32_t leaf_max = d.leaf_max ? d.leaf_max : 4;
             double box_cost = 1.0;
@@ -587,39 +767,55 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                     s.n_global = static_cast<uint32_t>(n);
                 }
             }
-            TreeBuilder tb(prims, s.nodes, leaf_max, box_cost);
-            if (s.n_global) {
-                Box g;
-                g.reset();
-                for (uint32_t i = 0; i < s.n_global; ++i) g.grow(prims[i].lo, prims[i].hi);
-                NodeRec leaf;
-                std::memcpy(leaf.bmin, g.lo, 12);
-                std::memcpy(leaf.bmax, g.hi, 12);
-                leaf.info = kLeafFlag | 0u;
-                leaf.link = s.n_global;
-                if (s.n_global < n_prims) {
-                    NodeRec root;
-                    std::memcpy(root.bmin, all.lo, 12);
-                    std::memcpy(root.bmax, all.hi, 12);
-                    root.info = 0;
-                    root.link = 0;
-                    s.nodes.push_back(root);
-                    s.nodes.push_back(leaf);
-                    tb.build(s.n_global, n_prims, 1);
-                    s.nodes[0].link = static_cast<uint32_t>(s.nodes.size());
+            auto build_tree = [&](uint32_t depth_cap) {
+                s.nodes.clear();
+                TreeBuilder tb(prims, s.nodes, leaf_max, box_cost, depth_cap);
+                if (s.n_global) {
+                    Box g;
+                    g.reset();
+                    for (uint32_t i = 0; i < s.n_global; ++i) g.grow(prims[i].lo, prims[i].hi);
+                    NodeRec leaf;
+                    std::memcpy(leaf.bmin, g.lo, 12);
+                    std::memcpy(leaf.bmax, g.hi, 12);
+                    leaf.info = kLeafFlag | 0u;
+                    leaf.link = s.n_global;
+                    if (s.n_global < n_prims) {
+                        NodeRec root;
+                        std::memcpy(root.bmin, all.lo, 12);
+                        std::memcpy(root.bmax, all.hi, 12);
+                        root.info = 0;
+                        root.link = 0;
+                        s.nodes.push_back(root);
+                        s.nodes.push_back(leaf);
+                        tb.build(s.n_global, n_prims, 1);
+                        s.nodes[0].link = static_cast<uint32_t>(s.nodes.size());
+                    } else {
+                        s.nodes.push_back(leaf);
+                    }
+                    s.n_leaves = tb.leaves + 1;
+                    s.max_leaf_tris = tb.max_leaf;          // of the tree proper; the global leaf holds n_global
+                    s.depth = tb.depth + 1;
                 } else {
-                    s.nodes.push_back(leaf);
+                    tb.build(0, n_prims, 0);
+                    s.n_leaves = tb.leaves;
+                    s.max_leaf_tris = tb.max_leaf;
+                    s.depth = tb.depth;
                 }
-                s.n_leaves = tb.leaves + 1;
-                s.max_leaf_tris = tb.max_leaf;          // of the tree proper; the global leaf holds n_global
-                s.depth = tb.depth + 1;
-            } else {
-                tb.build(0, n_prims, 0);
-                s.n_leaves = tb.leaves;
-                s.max_leaf_tris = tb.max_leaf;
-                s.depth = tb.depth;
+            };
+            build_tree(64u);
+            finish_tree();
+            if (s.wide_depth > kMaxWideDepth) {
+                // the walk's stack holds 3 pending children per wide level: a tree that deep (a pathological scene) is
+                // rebuilt balanced, which halves its levels when the children are pulled up
+                uint32_t halvings = 0;
+                while ((1ull << halvings) < n_prims) ++halvings;
+                build_tree(halvings + 3u);
+                finish_tree();
+                if (s.wide_depth > kMaxWideDepth) return RTX_ERR_INTERNAL;
             }
         }
+        if (static_cast<uint64_t>(s.wide.size()) * sizeof(WideNode) >= (1ull << 31)) return RTX_ERR_UNSUPPORTED;
+        if (s.wide_depth > kMaxWideDepth) return RTX_ERR_INTERNAL;     // (RTX_ACCEL_BRUTE: log4(n / 16) levels)
         s.tris.resize(n_prims);
         std::vector<uint32_t> pos_of(n_prims);
         for (uint32_t i = 0; i < n_prims; ++i) {

@@ -16,8 +16,8 @@ namespace rtx {
 
 // One node of the threaded (pre-order, skip-linked) BVH stream: 8 dwords, fetched
 // by the kernel with one scalar 32-byte load.
-//   inner node : info = 0,            link = index of the node to continue with when the
-//                                     subtree is skipped (its first child is at index+1)
+//   inner node : info = index of its second child (< 2^30; its first child is at index+1; the reference-tree stream
+//                leaves 0 here), link = index of the node to continue with when the subtree is skipped
 //   leaf  node : info = 0x80000000|s, link = number of primitive records, s = first record;
 //                bit 30 (kSphereFlag) set when the records are spheres — a leaf holds one arm of
 //                Primitive only (src/tracer/primitives/mod.rs:40-43), so the kernel's dispatch on
@@ -47,6 +47,27 @@ inline std::vector<NodeDev> nodes_in_device_order(const std::vector<NodeRec> &v,
                          v[i].bmin[2] - inflate, v[i].bmax[2] + inflate, v[i].link, v[i].info};
     return out;
 }
+// One WIDE node of the walk the kernels run: four children tested per step, 32 dwords, fetched with two scalar 64-byte
+// loads.  Made from the binary tree above by pulling grandchildren up (wide_nodes_build), so every child box is the box
+// of a binary node (or of a run of a large leaf's primitives) — a superset chain over the same exact leaf boxes — and
+// the walk keeps its pending children on a small wave-uniform stack.
+//   box[c]  lo.x lo.y lo.z hi.x hi.y hi.z of child c (on the device moved outwards by cull_delta, like NodeDev)
+//   ref[c]  inner child: byte offset of its wide node (a multiple of 128, bit 31 clear)
+//           leaf child:  kLeafFlag | (kSphereFlag) | records << kWideLeafCountShift | first primitive record
+//                        (1..16 records: a larger leaf of the binary tree is cut into runs under wide nodes of its own)
+//           empty slot:  a leaf of 0 records; its box is a point far outside the scene (2^100 on every axis), which
+//                        practically no ray passes — and if one does, nothing is tested
+//   aux[c]  inner child: wide nodes of its subtree (the cut's cost proxy); leaf child: records
+struct WideNode {
+    float    box[4][6];
+    uint32_t ref[4];
+    uint32_t aux[4];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
+constexpr uint32_t kWideLeafCountShift = 25u, kWideLeafMax = 16u, kWideLeafFirstMask = (1u << kWideLeafCountShift) - 1u;
+constexpr uint32_t kWideStackLanes = 64u;   // the walk's stack lives in the 64 lanes of one vector register:
+constexpr uint32_t kMaxWideDepth = 20u;     // one entry + at most 3 more per level below it (prepare_scene rebuilds a deeper tree balanced)
+static_assert(1u + 3u * kMaxWideDepth <= kWideStackLanes, "stack bound");
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kSphereFlag = 0x40000000u;
 constexpr uint32_t kLeafIndexMask = 0x3FFFFFFFu;
@@ -85,6 +106,9 @@ struct PreparedScene {
     uint32_t n_spheres = 0;            // of which spheres
     uint32_t n_samples = 0;
     std::vector<NodeRec>  nodes;
+    std::vector<WideNode> wide;        // the same tree with four children per node: what the kernels walk (may be empty:
+                                       // a scene of global triangles only); wide[0] is the root
+    uint32_t wide_depth = 0;           // levels of wide nodes
     std::vector<NodeRec>  ref_nodes;   // the reference's own tree as a stream (empty when not built)
     std::vector<TriRec>   tris;        // primitive records (triangles and spheres) in leaf order
     std::vector<ShadeRec> shade;       // in caller order
@@ -96,16 +120,25 @@ struct PreparedScene {
     // eye: it absorbs the error of the multiply-based plane distances (at most 11.01 * 2^-24 of that magnitude in
     // position units, rtx_traverse.hpp), so that the box test needs no per-test widening.
     float cull_delta = 0.0f;
+    // per primary ray r: bounding box of its light points (lo xyz, hi xyz), and the margin of the tile shaft test,
+    // 2^-16 x the largest coordinate magnitude of scene, eye and light points (rtx_kernel.hip: shaft_cut)
+    std::vector<float>    light_boxes;
+    float shaft_delta = 0.0f;
     uint32_t n_global = 0;   // > 0: records [0, n_global) are the "global" triangles, stream = root, their leaf, the tree proper
     // one per global triangle, in TriRec clothing: v0 = v0, e1 = fl(e1 x e2), e2 = (|e1| x |e2| with plus signs, rounded
     // up), bmin[0] = the denominator's error allowance — what rtx_traverse.hpp: plane_rules_out needs
     std::vector<TriRec>   global_planes;
 };
 constexpr uint32_t kMaxGlobalPrims = 8u;
-constexpr uint64_t kMaxPrimitives = 1ull << 26;   // 64 B x 2^26 = 4 GiB of records: the limit of a 32-bit byte offset
+constexpr uint64_t kMaxPrimitives = 1ull << 25;   // a wide leaf ref holds a 25-bit record index (64 B x 2^25 = 2 GiB of records)
 
 // Returns RTX_OK or a negative RtxError.
 int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);
+
+// Four-child nodes from the binary stream `nodes` (pre-order, inner.info = second child) below record `root`; returns
+// the number of wide levels.  A root that is a leaf gives one wide node with one child.
+// prim_boxes: n x {lo xyz, hi xyz} of the primitive records in leaf order (to bound the runs of a large leaf).
+uint32_t wide_nodes_build(const std::vector<NodeRec> &nodes, uint32_t root, const float *prim_boxes, std::vector<WideNode> &out);
 
 // ---- pieces with their own tests ----
 void camera_new(const float eye[3], const float look_at[3], const float up[3],

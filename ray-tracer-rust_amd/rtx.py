@@ -99,6 +99,7 @@ _SIGS = {
     "rtx_tiles_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rtx_debug_wave_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u32p, u32p]),
     "rtx_launch_timings": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p]),
+    "rtx_debug_tile_descs": (C.c_int, [C.c_void_p, C.c_int, u32p, C.c_size_t]),
     "rtx_strerror": (C.c_char_p, [C.c_int]),
     "rtx_last_hip_error": (C.c_int, []),
     "rtx_scene_light_points": (C.c_int, [C.c_void_p, f32p]),
@@ -399,6 +400,17 @@ class Scene:
         if n < 0:
             raise RtxError(n, "rtx_launch_timings")
         return a[:n], b[:n]
+
+    def tile_descs(self, device=0):
+        """Diagnostics: uint32 [tiles, 4] {cost class, primary hits, flags, reserved} of the most recent launch."""
+        n = _lib.rtx_debug_tile_descs(self._h, device, None, 0)
+        if n < 0:
+            raise RtxError(n, "rtx_debug_tile_descs")
+        out = np.zeros((n, 4), np.uint32)
+        m = _lib.rtx_debug_tile_descs(self._h, device, out.ctypes.data_as(u32p), n)
+        if m < 0:
+            raise RtxError(m, "rtx_debug_tile_descs")
+        return out[:m]
 
     def tiles_rows(self, first_tile, tile_stride, tile_rows):
         return _lib.rtx_tiles_rows(self._h, first_tile, tile_stride, tile_rows)

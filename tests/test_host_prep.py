@@ -203,7 +203,7 @@ def test_gamma_thresholds_reproduce_quantise_exactly(rtx, orc, samples_half):
         assert kernel_rule(x) == exp
 
 
-def _check_stream(nodes, order, tris, n_tris):
+def _check_stream(nodes, order, tris, n_tris, second_child=True):
     """Structural validity of the pre-order skip-linked stream (what the kernel's loop relies on)."""
     LEAF = 0x80000000
     n = len(nodes)
@@ -225,8 +225,11 @@ def _check_stream(nodes, order, tris, n_tris):
             seen[ids] = True
             assert np.array_equal(lo, tmin[ids].min(axis=0)) and np.array_equal(hi, tmax[ids].max(axis=0))
             return i + 1, lo, hi
-        assert info == 0 and i + 1 < link <= n
+        assert i + 1 < link <= n
         nxt, lo1, hi1 = walk(i + 1)
+        # an inner node of the library's stream names its second child (the shaft cut descends by it); the
+        # reference-tree stream leaves the word zero
+        assert info == (nxt if second_child else 0)
         nxt2, lo2, hi2 = walk(nxt)
         assert nxt2 == link
         assert np.array_equal(lo, np.minimum(lo1, lo2)) and np.array_equal(hi, np.maximum(hi1, hi2))
@@ -285,7 +288,7 @@ def test_reference_tree_stream(rtx, orc, samples_half):
         assert info["n_ref_nodes"] == 2 * len(tris) - 1 == osc.node_count()
         ref = s.ref_nodes()
         _, order = s.nodes()
-        _check_stream(ref, order, tris, len(tris))
+        _check_stream(ref, order, tris, len(tris), second_child=False)
         leaves = ref[(ref[:, 7] & 0x80000000) != 0]
         assert (leaves[:, 3] == 1).all()
         assert np.array_equal(order[leaves[:, 7] & 0x7FFFFFFF], osc.leaf_order())
@@ -333,7 +336,7 @@ def test_global_triangles_sit_in_the_first_leaf(rtx, samples_half):
         info = s.info()
         nodes, order = s.nodes()
         assert info["n_global"] == 1 and int(order[0]) == len(tris) - 1            # the ground is the last primitive
-        assert int(nodes[0, 7]) == 0 and int(nodes[0, 3]) == info["n_nodes"]        # root: inner, skips to the end
+        assert int(nodes[0, 7]) == 2 and int(nodes[0, 3]) == info["n_nodes"]        # root: inner (second child: the tree proper), skips to the end
         assert int(nodes[1, 7]) == LEAF | 0 and int(nodes[1, 3]) == 1               # its first child: the global leaf
         assert not int(nodes[2, 7]) & LEAF                                          # then the root of the tree proper
         _check_stream(nodes, order, tris, len(tris))

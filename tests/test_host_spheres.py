@@ -60,8 +60,9 @@ def check_stream(nodes, order, boxes, kinds):
             assert np.array_equal(lo, boxes[ids, :3].min(axis=0)) and np.array_equal(hi, boxes[ids, 3:].max(axis=0))
             leaves.append(ids)
             return i + 1, lo, hi
-        assert info == 0 and i + 1 < link <= n
+        assert i + 1 < link <= n
         nxt, lo1, hi1 = walk(i + 1)
+        assert info == nxt           # an inner node names its second child
         nxt2, lo2, hi2 = walk(nxt)
         assert nxt2 == link
         assert np.array_equal(lo, np.minimum(lo1, lo2)) and np.array_equal(hi, np.maximum(hi1, hi2))

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Development tool: per-tile cost of the shading pass.  Needs a library built with EXTRA=-DRTX_EXPERIMENT_TIMELINE=1
+(every job adds its duration to its tile's descriptor); prints how the frame's workgroup-time splits over the tiles by
+the size of their cut.      python tools/tile_timeline.py [c3|c4|c5|c2]"""
+import importlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+rtx = importlib.import_module("ray-tracer-rust_amd")
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+W, H = {"c3": (1920, 1080), "c2": (1920, 1080), "c4": (4096, 4096), "c5": (4096, 4096)}[wl]
+T = rtx.gen_samples()
+if wl == "c5":
+    tris, rgb = rtx.synthetic_primitives(1000000)
+    scene = rtx.Scene(W, H, tris, rgb, T)
+else:
+    scene = rtx.default_scene([os.path.join(ROOT, "models", "bunny.obj" if wl == "c2" else "big_bunny.obj")], W, H, T)
+scene.upload(0)
+nb = scene.tiles_bytes(0, 1, 8)
+out = torch.zeros(nb, dtype=torch.uint8, device="cuda:0")
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    scene.render_tiles_device(0, 0, 1, 8, out.data_ptr(), nb, st, None)
+torch.cuda.synchronize()
+sched, shade = scene.launch_timings(0, 3)
+td = scene.tile_descs(0)
+cls, n_hit, flags, ticks = td[:, 0], td[:, 1], td[:, 2], td[:, 3].astype(np.float64)
+n_cut = (flags >> 8) & 0xFF
+us = ticks / 100.0
+work = n_hit > 0
+print(json.dumps({"workload": wl, "tiles": int(len(td)), "tiles_with_hits": int(work.sum()), "shade_ms": float(shade[-1]),
+                  "sched_ms": float(sched[-1]), "sum_job_us": float(us.sum()), "wg_time_available_us": float(shade[-1] * 1e3 * 1024),
+                  "busy_fraction": float(us.sum() / (shade[-1] * 1e3 * 1024))}))
+edges = [0, 1, 2, 4, 8, 16, 32, 64, 65]
+for a, b in zip(edges[:-1], edges[1:]):
+    m = work & (n_cut >= a) & (n_cut < b)
+    if m.any():
+        print("cut %2d..%2d: %6d tiles  %8.0f us total (%4.1f %%)  mean %7.2f us  max %7.2f us  mean hits %4.1f" % (
+            a, b - 1, int(m.sum()), us[m].sum(), 100 * us[m].sum() / us.sum(), us[m].mean(), us[m].max(), n_hit[m].mean()))
+top = np.argsort(-us)[:8]
+tx = (W + 7) // 8
+print("costliest tiles:", [(int(t % tx), int(t // tx), int(n_cut[t]), int(n_hit[t]), round(float(us[t]), 1)) for t in top])
