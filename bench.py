@@ -12,16 +12,24 @@ max-over-ranks of the elapsed time.  Total work is fixed as N grows: "scaling": 
 
 Inputs (triangles, BVH stream, sample table) are resident in HBM before the timed region; the
 output stays in HBM (torch tensor).  torch is plumbing here: device memory, stream, events,
-torch.distributed.  Every ray is traced by the HIP kernel behind the C ABI (include/rtx.h).
+torch.distributed.  Every ray is traced by the HIP kernels behind the C ABI (include/rtx.h).
 
 One JSON line on stdout (rank 0).  Besides the contract fields:
-  roofline      dominant kernel (shade_tiles_kernel, the shading pass of a launch) against the HBM
-                roof, as the contract asks, timed by the library's HIP events around that pass on the
-                launch's stream (rtx_launch_timings); algorithmic bytes defined in DESIGN.md §Roofline.
-                The kernel is FP32-VALU bound (the whole scene is L2-resident), so "roofline_valu"
-                (whole launch) is printed next to it.
-  cpu_baseline  the CPU oracle in faithful-BVH mode (= the reference's src/tracer algorithm,
-                "port") timed on this box's host cores on a bounded sample of the same frame.
+  roofline       dominant kernel (shade_tiles_kernel, the shading pass of a launch) against the HBM roof, as the
+                 contract asks, timed by the library's HIP events around that pass on the launch's stream
+                 (rtx_launch_timings); algorithmic bytes defined in DESIGN.md section 5.  The kernel is bound by
+                 instruction issue (vector and scalar), not by HBM — the whole scene is L2-resident — so
+                 "roofline_valu" (whole launch) is printed next to it.
+  cpu_baseline   the CPU oracle in faithful-BVH mode (= the reference's src/tracer algorithm, "port") timed on this
+                 box's host cores on a bounded sample of the same frame, with the reference's thread policy
+                 (num_cpus - 1, src/main.rs:269) applied to the cores this job may use.
+  parity         the rows the cpu_baseline leg rendered, compared byte for byte with the frame the LAST TIMED STEP
+                 left in HBM: the throughput number belongs to the right image.
+  frame_ms_incl_d2h   the same frame through rtx_render_rows into pinned host memory (the reference's timed region
+                 ends with the pixels in host memory, src/main.rs:291-295,305); never `value`.
+  host           what the CPU numbers were measured on.
+  scaling_config BASELINE configs[3] (big_bunny.obj 4096x4096, the configuration of the scaling curve), the same
+                 partition and timing, fewer steps.
 """
 import argparse
 import importlib
@@ -42,20 +50,22 @@ WORKLOADS = {
     "c3": dict(desc="configs[2]: big_bunny.obj 1920x1080", objs=["big_bunny.obj"], width=1920, height=1080),
     "c4": dict(desc="configs[3]: big_bunny.obj 4096x4096", objs=["big_bunny.obj"], width=4096, height=4096),
     "c1b": dict(desc="big_bunny.obj 256x256 (test size)", objs=["big_bunny.obj"], width=256, height=256),
-    # configs[4]; no cpu_baseline: the reference's O(n^2) BVH build is infeasible at 10^6 primitives
+    # configs[4]: the reference's O(n^2) BVH build is infeasible at 10^6 primitives: its cpu_baseline is the
+    # oracle's leaf-gated brute force on a fixed 64x64 centre crop
     "c5": dict(desc="configs[4]: synthetic 1M-triangle random mesh 4096x4096", objs=[], synthetic=1000000,
                width=4096, height=4096),
     "c5s": dict(desc="synthetic 100k-triangle random mesh 1024x1024 (reduced configs[4])", objs=[], synthetic=100000,
                 width=1024, height=1024),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak (counts an FMA as 2 flop)
+VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak = 1024 SIMD-32 x 32 lanes x 2 flop (FMA) x 2.4 GHz: reached with plain v_fma_f32
 FLOP_PER_TRI_TEST = 46         # full Möller–Trumbore path incl. the division
-FLOP_PER_BOX_TEST = 29         # conservative box test: 6 fma as 3 packed (12), 6 min/max, max3+min3 (4), add, fma (2), sub, mul, 2 cmp
+FLOP_PER_BOX_TEST = 29         # conservative box test: 6 fma (12), 6 min/max, max3+min3 (4), 2 compares, the rest of the vote
 BYTES_PER_HIT_REC = 48         # p_hit, normal, colour: written by probe_kernel, read once by shade_tiles_kernel
 BYTES_PER_TRI_REC = 36         # v0,e1,e2 consumed per test
 BYTES_PER_BOX_REC = 24         # bmin,bmax
 BYTES_PER_PIXEL_IO = 11        # 8 B of the sample table + 3 B framebuffer
+N_SIMD, N_CU, PEAK_GHZ = 1024, 256, 2.4
 
 
 def parse_args():
@@ -66,8 +76,9 @@ def parse_args():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's policy: usable cores - 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-config", action="store_true", help="skip the configs[3] line inside the JSON")
     ap.add_argument("--save-png", default="")
     # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo for the barrier and the reductions
     # (RCCL refuses two ranks on one device).  Not a measurement: the ranks share the device.
@@ -76,34 +87,91 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(wl, samples_np, seconds, threads):
-    """Oracle (faithful BVH = the reference's algorithm) on row tiles spread over the same frame."""
+def host_info():
+    """nproc, the cores this job may actually use (affinity and the cgroup's CPU quota), CPU model."""
+    nproc = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = nproc
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()
+            if a != "max":
+                quota = float(a) / float(b)
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"nproc": nproc, "affinity": affinity, "cgroup_cpu_quota": quota, "usable_cores": usable, "cpu_model": model}
+
+
+def cpu_baseline(wl, samples_np, seconds, threads, host, rtx):
+    """Oracle on a bounded sample of the same frame.  OBJ workloads: faithful BVH (= the reference's algorithm) on
+    2-row bands spread over the frame; returns the rows it rendered so that the caller can compare them with the GPU
+    frame.  Synthetic workloads: leaf-gated brute force on a fixed 64x64 centre crop."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     if threads <= 0:
-        threads = min(16, os.cpu_count() or 1)
+        threads = max(1, host["usable_cores"] - 1)          # src/main.rs:269: num_cpus::get() - 1 worker threads
     W, H = wl["width"], wl["height"]
-    sc = orclib.default_scene(wl["objs"], W, H, samples_np)
-    band = 2
-    n_bands = H // band
-    bits = max(1, (n_bands - 1).bit_length())
-    # bit-reversed band order: wherever the time budget stops it, the sample is spread evenly over the frame
-    order = sorted(range(n_bands), key=lambda b: int(format(b, "0%db" % bits)[::-1], 2))
-    rays, secs, rows = 0, 0.0, 0
-    for b in order:
-        t0 = time.perf_counter()
-        _, st = sc.render_rows(b * band, band, mode=orclib.MODE_BVH, nthreads=threads)
-        secs += time.perf_counter() - t0
-        rays += st["primary_rays"] + st["shadow_rays"]
-        rows += band
-        if secs >= seconds:
-            break
+    rendered = []                                            # (x0, y0, image block)
+    rays, secs = 0, 0.0
+    if wl.get("synthetic"):
+        tris, rgb = rtx.synthetic_primitives(wl["synthetic"])
+        sc = orclib.Scene(W, H, tris, rgb, samples_np, build_bvh=False)
+        side = 64
+        x0, y0 = W // 2 - side // 2, H // 2 - side // 2
+        done = 0
+        for r in range(side):                                # a row of the crop at a time, until the budget is spent
+            t0 = time.perf_counter()
+            img, st = sc.render_window(x0, y0 + r, side, 1, mode=orclib.MODE_LEAFBOX, nthreads=threads)
+            secs += time.perf_counter() - t0
+            rays += st["primary_rays"] + st["shadow_rays"]
+            rendered.append((x0, y0 + r, img))
+            done += 1
+            if secs >= seconds:
+                break
+        sample = ("%d of 64 rows of the fixed 64x64 centre crop (x %d.., y %d..), oracle leaf-gated brute force (the "
+                  "reference's O(n^2) tree cannot be built at this size; equal to its result for every ray without a "
+                  "-0.0 direction component), %d threads, %.1f s, %d rays; an EXTRAPOLATION of what the reference would "
+                  "do if it could build its tree" % (done, x0, y0, threads, secs, rays))
+        kind_note = "port-brute"
+    else:
+        sc = orclib.default_scene(wl["objs"], W, H, samples_np)
+        band = 2
+        n_bands = H // band
+        bits = max(1, (n_bands - 1).bit_length())
+        # bit-reversed band order: wherever the time budget stops it, the sample is spread evenly over the frame
+        order = sorted(range(n_bands), key=lambda b: int(format(b, "0%db" % bits)[::-1], 2))
+        rows = 0
+        for b in order:
+            t0 = time.perf_counter()
+            img, st = sc.render_rows(b * band, band, mode=orclib.MODE_BVH, nthreads=threads)
+            secs += time.perf_counter() - t0
+            rays += st["primary_rays"] + st["shadow_rays"]
+            rendered.append((0, b * band, img))
+            rows += band
+            if secs >= seconds:
+                break
+        sample = ("%d of %d rows of the same frame (2-row bands in bit-reversed order, evenly spread), oracle "
+                  "faithful-BVH mode, %d threads, %.1f s, %d rays" % (rows, H, threads, secs, rays))
+        kind_note = "port"
     sc.close()
     return {
-        "value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": "%d of %d rows of the same frame (2-row bands in bit-reversed order, evenly spread), oracle "
-                  "faithful-BVH mode, %d threads, %.1f s, %d rays" % (rows, H, threads, secs, rays),
-    }
+        "value": float("%.6g" % (rays / secs / 1e6)), "unit": "Mrays/s", "cores": host["usable_cores"], "threads": threads,
+        "kind": "port", "mode": kind_note, "thread_policy": "usable cores - 1 (src/main.rs:269: num_cpus - 1)",
+        "sample": sample,
+    }, rendered
 
 
 def reduce_counters(counters, world, via_host=False):
@@ -123,6 +191,82 @@ def reduce_times(values, world, device):
         import torch.distributed as dist
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return tt.cpu().tolist()
+
+
+class Run:
+    """One workload on this rank's share of the frame: scene in HBM, counted launch, timed launches."""
+
+    def __init__(self, rtx, wl, samples, rank, world, local_rank, dev, tile_rows):
+        self.rtx, self.wl, self.rank, self.world, self.local_rank, self.dev, self.tile_rows = rtx, wl, rank, world, local_rank, dev, tile_rows
+        W, H = wl["width"], wl["height"]
+        if wl.get("synthetic"):
+            tris, rgb = rtx.synthetic_primitives(wl["synthetic"])
+            self.scene = rtx.Scene(W, H, tris, rgb, samples)
+            self.asset = "synthetic mesh (splitmix64 seed %d)" % rtx.SYNTHETIC_SEED
+        else:
+            self.scene = rtx.default_scene([os.path.join(ROOT, "models", o) for o in wl["objs"]], W, H, samples)
+            self.asset = "reference asset models/%s" % wl["objs"][0]
+        self.info = self.scene.info()
+        self.scene.upload(local_rank)                      # inputs resident in HBM before timing
+        self.nbytes = self.scene.tiles_bytes(rank, world, tile_rows)
+        self.out = torch.zeros(max(self.nbytes, 16), dtype=torch.uint8, device=dev)
+        self.counters = torch.zeros(8, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.current_stream(dev)
+
+    def step(self, count=False):
+        self.scene.render_tiles_device(self.local_rank, self.rank, self.world, self.tile_rows, self.out.data_ptr(), self.nbytes,
+                                       self.stream.cuda_stream, self.counters.data_ptr() if count else None)
+
+    def barrier(self):
+        torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(self.dev)
+
+    def counted(self, via_host):
+        self.step(count=True)                               # one counted launch, outside the timed region
+        torch.cuda.synchronize(self.dev)
+        return reduce_counters(self.counters, self.world, via_host)
+
+    def timed(self, steps, warmup, via_host):
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record(self.stream)
+            self.step()
+            e1.record(self.stream)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, steps)   # this rank's launches
+        # the launch is two passes; the library brackets them with HIP events on the launch's stream
+        # (rtx_launch_timings): these are the timed region's own launches, newest last
+        sched_t, shade_t = self.scene.launch_timings(self.local_rank, min(steps, 64))
+        sched_ms = float(sched_t.mean()) if len(sched_t) else 0.0
+        shade_ms = float(shade_t.mean()) if len(shade_t) else kernel_ms
+        return reduce_times((elapsed, kernel_ms / 1e3, sched_ms / 1e3, shade_ms / 1e3), self.world,
+                            torch.device("cpu") if via_host else self.dev)
+
+    def frame(self):
+        """This rank's share of the frame, as the last launch left it in HBM, scattered into a whole frame."""
+        W, H = self.wl["width"], self.wl["height"]
+        frame = np.zeros((H, W, 3), np.uint8)
+        self.rtx.scatter_tiles(frame, self.out[:self.nbytes].cpu().numpy().reshape(-1, W, 3), self.rank, self.world, self.tile_rows)
+        return frame
+
+    def incl_d2h_ms(self, steps):
+        """Whole frame through rtx_render_rows into pinned host memory: launch + D2H + synchronise, per frame."""
+        W, H = self.wl["width"], self.wl["height"]
+        pinned = torch.empty(H * W * 3, dtype=torch.uint8, pin_memory=True)
+        for _ in range(2):
+            self.scene.render_rows(0, H, device=self.local_rank, out_ptr=pinned.data_ptr())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.scene.render_rows(0, H, device=self.local_rank, out_ptr=pinned.data_ptr())
+        return (time.perf_counter() - t0) / steps * 1e3, pinned.numpy().reshape(H, W, 3)
 
 
 def main():
@@ -153,66 +297,45 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
     samples = rtx.gen_samples()
-    if wl.get("synthetic"):
-        tris, rgb = rtx.synthetic_primitives(wl["synthetic"])
-        scene = rtx.Scene(W, H, tris, rgb, samples)
-        asset = "synthetic mesh (splitmix64 seed %d)" % rtx.SYNTHETIC_SEED
-    else:
-        scene = rtx.default_scene([os.path.join(ROOT, "models", o) for o in wl["objs"]], W, H, samples)
-        asset = "reference asset models/%s" % wl["objs"][0]
-    info = scene.info()
-    scene.upload(local_rank)                               # inputs resident in HBM before timing
+    host = host_info()
+    run = Run(rtx, wl, samples, rank, world, local_rank, dev, args.tile_rows)
+    info = run.info
 
-    tile_rows = args.tile_rows
-    nbytes = scene.tiles_bytes(rank, world, tile_rows)
-    out = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    counters = torch.zeros(8, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    def step(count=False):
-        scene.render_tiles_device(local_rank, rank, world, tile_rows, out.data_ptr(), nbytes,
-                                  stream.cuda_stream, counters.data_ptr() if count else None)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    # one counted launch (outside the timed region) gives the frame's ray / test counts
-    step(count=True)
-    torch.cuda.synchronize(dev)
-    c = reduce_counters(counters, world, via_host)
+    c = run.counted(via_host)
     primary_hits, box_tests, tri_tests, node_visits, tri_visits = c[0], c[1], c[2], c[3], c[4]
     sched_node_visits, sched_tri_visits = c[6], c[7]       # the scheduling pass's (primary rays') share of the fetches
     primary_rays = W * H * rtx.NB_RAY
     r_total = primary_rays + rtx.NB_LIGHT_SAMPLE * primary_hits
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record(stream)
-        step()
-        e1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)   # this rank's launches
-    # the launch is two passes; the library brackets them with HIP events on the launch's stream (rtx_launch_timings):
-    # these are the timed region's own launches, newest last
-    sched_t, shade_t = scene.launch_timings(local_rank, min(args.steps, 64))
-    sched_ms = float(sched_t.mean()) if len(sched_t) else 0.0
-    shade_ms = float(shade_t.mean()) if len(shade_t) else kernel_ms
-    elapsed, kernel_s, sched_s, shade_s = reduce_times(
-        (elapsed, kernel_ms / 1e3, sched_ms / 1e3, shade_ms / 1e3), world, torch.device("cpu") if via_host else dev)
+    elapsed, kernel_s, sched_s, shade_s = run.timed(args.steps, args.warmup, via_host)
     ms_per_step = elapsed / args.steps * 1e3
+    gpu_frame = run.frame() if world == 1 else None         # what the last timed step left in HBM
 
     if args.save_png and world == 1:
-        frame = np.zeros((H, W, 3), np.uint8)
-        rtx.scatter_tiles(frame, out[:nbytes].cpu().numpy().reshape(-1, W, 3), rank, world, tile_rows)
-        rtx.write_png(args.save_png, frame)
+        rtx.write_png(args.save_png, gpu_frame)
+
+    incl_d2h = None
+    if world == 1:
+        d2h_ms, host_frame = run.incl_d2h_ms(max(3, min(args.steps, 10)))
+        incl_d2h = {"frame_ms_incl_d2h": round(d2h_ms, 4),
+                    "what": "rtx_render_rows of the whole frame into pinned host memory: launch + %d-byte D2H + "
+                            "synchronise, wall clock per frame" % (W * H * 3),
+                    "same_bytes_as_timed_frame": bool(np.array_equal(host_frame, gpu_frame))}
+
+    # BASELINE configs[3] — the configuration of the scaling curve — inside the same line
+    scaling = None
+    if args.workload == "c3" and not args.no_scaling_config:
+        wl4 = WORKLOADS["c4"]
+        run4 = Run(rtx, wl4, samples, rank, world, local_rank, dev, args.tile_rows)
+        c4 = run4.counted(via_host)
+        steps4 = max(3, args.steps // 2)
+        e4, k4, s4, h4 = run4.timed(steps4, min(args.warmup, 2), via_host)
+        r4 = wl4["width"] * wl4["height"] * rtx.NB_RAY + rtx.NB_LIGHT_SAMPLE * c4[0]
+        ms4 = e4 / steps4 * 1e3
+        scaling = {"workload": wl4["desc"], "n_gpus": world, "steps": steps4, "ms_per_step": round(ms4, 4),
+                   "value": round(r4 / (ms4 / 1e3) / 1e6, 3), "unit": "Mrays/s", "rays_per_frame": r4,
+                   "schedule_ms": round(s4 * 1e3, 4), "shade_ms": round(h4 * 1e3, 4)}
+        run4.scene.close()
 
     if rank == 0:
         mrays = r_total / (ms_per_step / 1e3) / 1e6
@@ -245,9 +368,9 @@ def main():
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32",
-            "data": "%s + seeded sample table (splitmix64 seed %d); no dataset download" % (asset, rtx.DEFAULT_SEED),
+            "data": "%s + seeded sample table (splitmix64 seed %d); no dataset download" % (run.asset, rtx.DEFAULT_SEED),
             "config": {"workload": wl["desc"] + ", 1 spp, 100 light samples, default scene of src/main.rs:327-358",
-                       "width": W, "height": H, "n_tris": info["n_tris"], "tile_rows": tile_rows,
+                       "width": W, "height": H, "n_tris": info["n_tris"], "tile_rows": args.tile_rows,
                        "partition": "row tiles, tile t -> rank t %% %d, no collective" % world +
                                     (" (REHEARSAL: all ranks on one device)" if args.ranks_share_device_0 and world > 1 else ""),
                        "accel": "sah-bvh leaf<=%d, %d nodes" % (info["max_leaf_tris"], info["n_nodes"])},
@@ -264,31 +387,51 @@ def main():
                                     "launch_ms": round(kernel_s * 1e3, 4),
                                     "survey_8d_bytes": int(launch_alg_bytes),
                                     "survey_8d_gbs": round(launch_alg_bytes / kernel_s / 1e9, 3)},
-                         "note": "scene records %.2f MB (L2-resident when < 4 MB): the kernel is FP32-VALU / latency bound, "
-                                 "see roofline_valu; survey_b_alg_* = SURVEY 8(d) brute-force-equivalent bytes"
-                                 % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),
+                         "note": "scene records %.2f MB (L2-resident when < 4 MB): the kernel is bound by instruction issue "
+                                 "and scalar-load latency, not HBM, see roofline_valu; survey_b_alg_* = SURVEY 8(d) "
+                                 "brute-force-equivalent bytes" % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),
                          "redo_tiles": c[5],
                          "survey_b_alg_bytes": int(b_alg_brute),
                          "survey_b_alg_frac": round(b_alg_brute / world / kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline_valu": {"bound": "fp32-valu", "achieved": round(ach_tf, 3), "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
-                              # 157.3 counts packed FMAs (2 lanes-ops x 2 flop); this path may neither fuse (bit parity)
-                              # nor pack much: one f32 op per lane per 4 cycles per SIMD = 39.3 Tflop/s
-                              "peak_unfused_unpacked": VALU_PEAK_TFLOPS / 4,
-                              "frac_unfused_unpacked": round(ach_tf / (VALU_PEAK_TFLOPS / 4), 5),
+                              # MI355X_MICROARCH.md: SIMD-32, a wave64 v_fma_f32 issues in 2 cycles; 157.3 TFLOP/s is reached
+                              # with plain FMAs.  Pixel arithmetic here may not fuse (bit parity with the reference), so
+                              # one flop per lane-slot: 78.6 Tflop/s is the ceiling of this instruction mix
+                              "peak_unfused": VALU_PEAK_TFLOPS / 2,
+                              "frac_unfused": round(ach_tf / (VALU_PEAK_TFLOPS / 2), 5),
                               "pmc": pmc,
                               "box_tests": box_tests, "tri_tests": tri_tests,
                               "wave_node_visits": node_visits, "wave_tri_visits": tri_visits},
+            "host": host,
         }
-        if world == 1 and not args.no_cpu_baseline and not wl.get("synthetic"):
-            line["cpu_baseline"] = cpu_baseline(wl, samples, args.cpu_seconds, args.cpu_threads)
-            line["cpu_baseline"]["gpu_over_cpu"] = round(mrays / line["cpu_baseline"]["value"], 1)
+        if incl_d2h:
+            line.update(incl_d2h)
+        if scaling:
+            line["scaling_config"] = scaling
+        if world == 1 and not args.no_cpu_baseline:
+            base, rendered = cpu_baseline(wl, samples, args.cpu_seconds, args.cpu_threads, host, rtx)
+            base["gpu_over_cpu"] = round(mrays / base["value"], 1)
+            line["cpu_baseline"] = base
+            # the oracle's pixels against the frame of the last timed step
+            px_diff, max_abs, n_px = 0, 0, 0
+            for x0, y0, img in rendered:
+                got = gpu_frame[y0:y0 + img.shape[0], x0:x0 + img.shape[1]]
+                d = np.abs(got.astype(np.int32) - img.astype(np.int32))
+                px_diff += int((d.max(axis=2) > 0).sum())
+                max_abs = max(max_abs, int(d.max()))
+                n_px += img.shape[0] * img.shape[1]
+            line["parity"] = {"rows" if not wl.get("synthetic") else "crop_rows": len(rendered) * (1 if wl.get("synthetic") else 2),
+                              "pixels": n_px, "max_abs_diff": max_abs, "px_diff": px_diff,
+                              "checked": "oracle pixels of the cpu_baseline sample vs the frame the last timed step left in HBM"}
         else:
             line["cpu_baseline"] = None
+            line["parity"] = None
         print(json.dumps(line), flush=True)
 
-    scene.close()
+    run.scene.close()
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

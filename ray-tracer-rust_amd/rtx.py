@@ -361,13 +361,17 @@ class Scene:
     def upload(self, device=0):
         _check(_lib.rtx_scene_upload(self._h, device), "rtx_scene_upload")
 
-    def render_rows(self, row0=0, nrows=None, device=0, stats=False):
+    def render_rows(self, row0=0, nrows=None, device=0, stats=False, out_ptr=None):
+        """out_ptr: address of a caller-owned host buffer of nrows*width*3 bytes (e.g. pinned memory) to render into
+        instead of a fresh numpy array; the call then returns None (or the statistics)."""
         if nrows is None:
             nrows = self.height - row0
-        out = np.zeros((nrows, self.width, 3), np.uint8)
+        out = None if out_ptr else np.zeros((nrows, self.width, 3), np.uint8)
         st = Stats()
-        _check(_lib.rtx_render_rows(self._h, device, row0, nrows, out.ctypes.data, C.byref(st) if stats else None),
-               "rtx_render_rows")
+        _check(_lib.rtx_render_rows(self._h, device, row0, nrows, C.c_void_p(out_ptr) if out_ptr else out.ctypes.data,
+                                    C.byref(st) if stats else None), "rtx_render_rows")
+        if out_ptr:
+            return st.asdict() if stats else None
         return (out, st.asdict()) if stats else out
 
     def render_frame(self, devices=(0,), tile_rows=8, stats=False):

@@ -16,7 +16,7 @@ python3 "$ROOT/bench.py" --workload "$WL" --steps 30 --warmup 3 > "$OUT/bench_$W
 echo "bench: $(cut -c1-200 "$OUT/bench_$WL.json")"
 
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$WL" -- \
-    python3 "$ROOT/bench.py" --workload "$WL" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/stats_$WL.log" 2>&1 || { echo "kernel-trace failed"; exit 1; }
+    python3 "$ROOT/bench.py" --workload "$WL" --steps 20 --warmup 3 --no-cpu-baseline --no-scaling-config > "$OUT/stats_$WL.log" 2>&1 || { echo "kernel-trace failed"; exit 1; }
 echo "kernel stats done"
 
 i=0
@@ -26,7 +26,7 @@ for group in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ
              "FETCH_SIZE" "WRITE_SIZE"; do
     # shellcheck disable=SC2086
     timeout -k 10 400 rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OUT/pmc$i" -o "$WL" -- \
-        python3 "$ROOT/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc$i.log" 2>&1 || { echo "pmc group $i failed"; tail -3 "$OUT/pmc$i.log"; exit 1; }
+        python3 "$ROOT/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-config > "$OUT/pmc$i.log" 2>&1 || { echo "pmc group $i failed"; tail -3 "$OUT/pmc$i.log"; exit 1; }
     echo "pmc group $i done: $group"
     i=$((i + 1))
 done
