@@ -158,7 +158,10 @@ int rtx_render_rows(RtxScene *scene, int device, uint32_t row0, uint32_t nrows,
                     uint8_t *out_rgb, RtxStats *stats);
 
 /* Whole frame, row tiles of `tile_rows` rows dealt round-robin to devices[0..n_devices)
- * (tile t -> devices[t % n_devices]); out_rgb is height*width*3 bytes, host. */
+ * (tile t -> devices[t % n_devices]); out_rgb is height*width*3 bytes, host.  A device may be named more than
+ * once: its shares are rendered one after another (how the multi-share path is rehearsed on one GPU).  Device locks
+ * are taken in ascending device order whatever the order of the array; on an error the launches and copies already
+ * in flight are waited for before the call returns. */
 int rtx_render_frame(RtxScene *scene, const int *devices, int n_devices, uint32_t tile_rows,
                      uint8_t *out_rgb, RtxStats *stats);
 
@@ -173,7 +176,7 @@ int rtx_render_frame(RtxScene *scene, const int *devices, int n_devices, uint32_
 int rtx_render_tiles_device(RtxScene *scene, int device, uint32_t first_tile, uint32_t tile_stride,
                             uint32_t tile_rows, void *d_out_rgb, size_t d_out_bytes,
                             void *stream, uint64_t *d_counters);
-/* rows / bytes the call above produces */
+/* rows / bytes the call above produces; rtxh_scatter_tiles puts such a packed share back into a frame */
 uint32_t rtx_tiles_rows(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows);
 size_t   rtx_tiles_bytes(const RtxScene *scene, uint32_t first_tile, uint32_t tile_stride, uint32_t tile_rows);
 
@@ -247,6 +250,11 @@ void rtxh_free(void *p);
 int  rtxh_ref_leaf_rank(uint32_t n_tris, const float *v0v1v2, uint32_t *out_rank);
 /* seeded stand-in for the thread_rng table (src/main.rs:260-265): splitmix64, 24-bit floats */
 void rtxh_gen_samples(uint64_t seed, uint32_t n_pairs, float *out);
+/* Places the packed rows of one share (row tiles first_tile, first_tile + tile_stride, ... of tile_rows rows, clipped to
+ * the frame, one after another in `packed`: what rtx_render_tiles_device writes) into their rows of a height x width
+ * RGB8 frame — the gather of src/main.rs:291-295 with disjoint row ranges in place of the Mutex<DynamicImage>. */
+int  rtxh_scatter_tiles(uint8_t *frame, uint32_t height, uint32_t width, const uint8_t *packed, uint32_t first_tile,
+                        uint32_t tile_stride, uint32_t tile_rows);
 /* RGB8 PNG (what img.save(.., image::PNG) produces on decode, src/main.rs:313-315) */
 int  rtxh_write_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
 /* BASELINE.json configs[4], "synthetic 1M-triangle random mesh": n_tris triangles whose centroid is uniform in

@@ -8,6 +8,7 @@
 #include <array>
 #include <fstream>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../include/rtx.h"
@@ -94,7 +95,7 @@ void rtxh_camera_new(const float eye[3], const float look_at[3], const float up[
 // import_obj — src/main.rs:114-149.  Only "v x y z" and "f i j k" lines mean anything; face
 // indices are 1-based into the vertices read so far.  Where the reference would panic
 // (unparsable number, index out of range, fewer than four tokens) this returns RTX_ERR_IO.
-int rtxh_import_obj(const char *path, float **v0v1v2)
+static int import_obj_impl(const char *path, float **v0v1v2)
 {
     if (!path || !v0v1v2) return RTX_ERR_BAD_ARG;
     *v0v1v2 = nullptr;
@@ -174,7 +175,7 @@ bool read_mtl(const std::string &path, std::vector<std::pair<std::string, std::a
 
 extern "C" {
 
-int rtxh_import_obj_ex(const char *path, uint32_t flags, float **v0v1v2, float **rgb)
+static int import_obj_ex_impl(const char *path, uint32_t flags, float **v0v1v2, float **rgb)
 {
     if (!path || !v0v1v2 || (flags & ~RTXH_OBJ_ALL)) return RTX_ERR_BAD_ARG;
     *v0v1v2 = nullptr;
@@ -365,6 +366,51 @@ int rtxh_write_png(const char *path, uint32_t width, uint32_t height, const uint
     } catch (...) {
         return RTX_ERR_OOM;
     }
+}
+
+// Nothing may unwind through the C ABI into a Rust or C caller: a large or hostile OBJ can make a vector or a string
+// throw (bad_alloc, length_error).
+int rtxh_import_obj(const char *path, float **v0v1v2)
+{
+    try {
+        return import_obj_impl(path, v0v1v2);
+    } catch (const std::bad_alloc &) {
+        if (v0v1v2) *v0v1v2 = nullptr;
+        return RTX_ERR_OOM;
+    } catch (...) {
+        if (v0v1v2) *v0v1v2 = nullptr;
+        return RTX_ERR_INTERNAL;
+    }
+}
+
+int rtxh_import_obj_ex(const char *path, uint32_t flags, float **v0v1v2, float **rgb)
+{
+    try {
+        return import_obj_ex_impl(path, flags, v0v1v2, rgb);
+    } catch (const std::bad_alloc &) {
+        if (v0v1v2) *v0v1v2 = nullptr;
+        if (rgb) *rgb = nullptr;
+        return RTX_ERR_OOM;
+    } catch (...) {
+        if (v0v1v2) *v0v1v2 = nullptr;
+        if (rgb) *rgb = nullptr;
+        return RTX_ERR_INTERNAL;
+    }
+}
+
+int rtxh_scatter_tiles(uint8_t *frame, uint32_t height, uint32_t width, const uint8_t *packed, uint32_t first_tile,
+                       uint32_t tile_stride, uint32_t tile_rows)
+{
+    if (!frame || !packed || !tile_rows || !tile_stride) return RTX_ERR_BAD_ARG;
+    const size_t row_bytes = static_cast<size_t>(width) * 3u;
+    size_t ly = 0;
+    for (uint64_t t = first_tile; t * tile_rows < height; t += tile_stride) {
+        const size_t r0 = static_cast<size_t>(t * tile_rows);
+        const size_t n = (height - r0 < tile_rows) ? height - r0 : tile_rows;
+        std::memcpy(frame + r0 * row_bytes, packed + ly * row_bytes, n * row_bytes);
+        ly += n;
+    }
+    return RTX_OK;
 }
 
 }  // extern "C"

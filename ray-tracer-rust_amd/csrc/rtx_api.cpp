@@ -5,6 +5,7 @@
 // exists in this library; without a HIP device every render entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -124,10 +125,9 @@ uint32_t kernel_variant()
 #endif
 }
 
-// caller holds st.mu and has the device current
-int ensure_uploaded(RtxScene *scene, DeviceState &st)
+// the uploads of ensure_uploaded; may stop half way
+int upload_all(RtxScene *scene, DeviceState &st)
 {
-    if (st.uploaded) return RTX_OK;
     const rtx::PreparedScene &p = scene->prep;
     int rc;
     const float inflate = RTX_CULL_INFLATED ? p.cull_delta : 0.0f;
@@ -157,6 +157,32 @@ int ensure_uploaded(RtxScene *scene, DeviceState &st)
         for (hipEvent_t &e : slot) RTX_HIP(hipEventCreate(&e));
     st.uploaded = true;
     return RTX_OK;
+}
+
+// what upload_all allocated so far goes back when it fails half way (the caller may retry: nothing may leak)
+void release_uploads(DeviceState &st)
+{
+    void **bufs[] = {&st.nodes, &st.wide, &st.ref_nodes, &st.tris, &st.shade, &st.samples, &st.lights, &st.thr, &st.planes, &st.light_boxes,
+                     reinterpret_cast<void **>(&st.d_counters)};
+    for (void **b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    if (st.ev0) { (void)hipEventDestroy(st.ev0); st.ev0 = nullptr; }
+    if (st.ev1) { (void)hipEventDestroy(st.ev1); st.ev1 = nullptr; }
+    for (auto &slot : st.ring)
+        for (hipEvent_t &e : slot)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (st.stream) { (void)hipStreamDestroy(st.stream); st.stream = nullptr; }
+}
+
+// caller holds st.mu and has the device current
+int ensure_uploaded(RtxScene *scene, DeviceState &st)
+{
+    if (st.uploaded) return RTX_OK;
+    const int rc = upload_all(scene, st);
+    if (rc != RTX_OK) release_uploads(st);
+    return rc;
 }
 
 rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
@@ -192,7 +218,8 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     return S;
 }
 
-int ensure_out(DeviceState &st, size_t bytes, bool need_stage)
+// device output buffer of at least `bytes`, pinned staging buffer of at least `stage_bytes` (0: none needed)
+int ensure_out(DeviceState &st, size_t bytes, size_t stage_bytes)
 {
     if (st.d_out_cap < bytes) {
         if (st.d_out) RTX_HIP(hipFree(st.d_out));
@@ -201,12 +228,12 @@ int ensure_out(DeviceState &st, size_t bytes, bool need_stage)
         RTX_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_out), bytes));
         st.d_out_cap = bytes;
     }
-    if (need_stage && st.h_stage_cap < bytes) {
+    if (st.h_stage_cap < stage_bytes) {
         if (st.h_stage) RTX_HIP(hipHostFree(st.h_stage));
         st.h_stage = nullptr;
         st.h_stage_cap = 0;
-        RTX_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.h_stage), bytes, hipHostMallocDefault));
-        st.h_stage_cap = bytes;
+        RTX_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.h_stage), stage_bytes, hipHostMallocDefault));
+        st.h_stage_cap = stage_bytes;
     }
     return RTX_OK;
 }
@@ -285,12 +312,12 @@ void fill_stats(RtxStats *s, const RtxScene *scene, uint64_t pixels, const unsig
 }
 
 // launch one device's share; caller holds st.mu and has the device current
-int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool count, bool stage)
+int launch_on(RtxScene *scene, DeviceState &st, const rtx::TileSpec &ts, bool count)
 {
     int rc = ensure_uploaded(scene, st);
     if (rc != RTX_OK) return rc;
     const size_t bytes = static_cast<size_t>(ts.local_rows) * scene->prep.width * 3u;
-    if ((rc = ensure_out(st, bytes ? bytes : 16, stage)) != RTX_OK) return rc;
+    if ((rc = ensure_out(st, bytes ? bytes : 16, 0)) != RTX_OK) return rc;
     const rtx::DeviceScene S = device_scene(scene, st);
     if ((rc = ensure_redo(st, rtx::trace_redo_bytes(S, ts))) != RTX_OK) return rc;
     const rtx::StreamWorkspace *ws = nullptr;
@@ -417,7 +444,7 @@ int rtx_render_rows(RtxScene *scene, int device, uint32_t row0, uint32_t nrows, 
         return RTX_OK;
     }
     const rtx::TileSpec ts{row0, nrows, nrows, nrows};
-    if ((rc = launch_on(scene, *st, ts, stats != nullptr, false)) != RTX_OK) return rc;
+    if ((rc = launch_on(scene, *st, ts, stats != nullptr)) != RTX_OK) return rc;
     const size_t bytes = static_cast<size_t>(nrows) * W * 3u;
     RTX_HIP(hipMemcpyAsync(out_rgb, st->d_out, bytes, hipMemcpyDeviceToHost, st->stream));
     unsigned long long c[rtx::kNumCounters] = {0};
@@ -436,58 +463,107 @@ int rtx_render_frame(RtxScene *scene, const int *devices, int n_devices, uint32_
                      uint8_t *out_rgb, RtxStats *stats)
 {
     if (!scene || !devices || n_devices <= 0 || !tile_rows || !out_rgb) return RTX_ERR_BAD_ARG;
-    for (int a = 0; a < n_devices; ++a)
-        for (int b = a + 1; b < n_devices; ++b)
-            if (devices[a] == devices[b]) return RTX_ERR_BAD_ARG;
+    // first_row / stride of a share are 32-bit row numbers (rtx_render_tiles_device checks the same)
+    if (static_cast<uint64_t>(n_devices) * tile_rows > 0xFFFFFFFFull) return RTX_ERR_BAD_ARG;
     const uint32_t H = scene->prep.height, W = scene->prep.width;
     const size_t row_bytes = static_cast<size_t>(W) * 3u;
     const double t0 = wall_ms();
-    std::vector<DeviceState *> sts(n_devices, nullptr);
-    std::vector<std::unique_lock<std::mutex>> locks;
-    std::vector<rtx::TileSpec> specs(n_devices);
-    for (int j = 0; j < n_devices; ++j) {
-        int rc = get_state(scene, devices[j], &sts[j]);
+    // Share j = row tiles j, j + n, ... goes to devices[j].  A device may be named more than once: its shares are
+    // then rendered one after another on its stream (this is also how the path is rehearsed on a one-GPU box).
+    struct Share { DeviceState *st; rtx::TileSpec spec; size_t stage_offset; };
+    std::vector<Share> shares(static_cast<size_t>(n_devices));
+    std::map<int, DeviceState *> unique;                   // ascending device id: the order the locks are taken in, so
+    for (int j = 0; j < n_devices; ++j) {                  // that concurrent calls naming {0,1} and {1,0} cannot deadlock
+        DeviceState *st = nullptr;
+        const int rc = get_state(scene, devices[j], &st);
         if (rc != RTX_OK) return rc;
-        locks.emplace_back(sts[j]->mu);
+        shares[j].st = st;
+        unique[devices[j]] = st;
     }
-    // launch everywhere first (asynchronous), then gather
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (auto &kv : unique) locks.emplace_back(kv.second->mu);
+    // per device: the largest share (device buffer) and the sum of its shares (pinned staging), sized BEFORE anything is
+    // in flight — growing a buffer later would free memory a copy is still reading
+    std::map<DeviceState *, std::pair<size_t, size_t>> need;
     for (int j = 0; j < n_devices; ++j) {
         const uint32_t rows = tiles_rows(H, static_cast<uint32_t>(j), static_cast<uint32_t>(n_devices), tile_rows);
-        specs[j] = rtx::TileSpec{static_cast<uint32_t>(j) * tile_rows, tile_rows,
-                                 static_cast<uint32_t>(n_devices) * tile_rows, rows};
-        if (!rows) continue;
-        DeviceGuard g(devices[j]);
-        RTX_HIP(g.status());
-        int rc = launch_on(scene, *sts[j], specs[j], stats != nullptr, true);
+        shares[j].spec = rtx::TileSpec{static_cast<uint32_t>(j) * tile_rows, tile_rows,
+                                       static_cast<uint32_t>(n_devices) * tile_rows, rows};
+        auto &n = need[shares[j].st];
+        shares[j].stage_offset = n.second;
+        n.first = std::max(n.first, rows * row_bytes);
+        n.second += rows * row_bytes;
+    }
+    // on any failure: wait for what was already launched (kernels and copies into our staging buffers) before returning
+    std::vector<int> launched;
+    auto fail = [&](int rc) {
+        for (int d : launched) {
+            DeviceGuard g(d);
+            if (g.status() == hipSuccess) (void)hipStreamSynchronize(unique[d]->stream);
+        }
+        return rc;
+    };
+    for (auto &kv : unique) {
+        DeviceGuard g(kv.first);
+        if (g.status() != hipSuccess) { g_last_hip_error = static_cast<int>(g.status()); return RTX_ERR_HIP; }
+        const auto &n = need[kv.second];
+        const int rc = ensure_out(*kv.second, n.first ? n.first : 16, n.second ? n.second : 16);
         if (rc != RTX_OK) return rc;
-        RTX_HIP(hipMemcpyAsync(sts[j]->h_stage, sts[j]->d_out, rows * row_bytes, hipMemcpyDeviceToHost, sts[j]->stream));
     }
+    // launch everywhere first (asynchronous), then gather
     unsigned long long total[rtx::kNumCounters] = {0};
-    double kernel_ms = 0.0;
+    std::vector<unsigned long long> counters(static_cast<size_t>(n_devices) * rtx::kNumCounters, 0ull);
+    std::vector<float> share_ms(static_cast<size_t>(n_devices), 0.0f);
     for (int j = 0; j < n_devices; ++j) {
-        if (!specs[j].local_rows) continue;
+        Share &sh = shares[j];
+        if (!sh.spec.local_rows) continue;
         DeviceGuard g(devices[j]);
-        RTX_HIP(g.status());
-        unsigned long long c[rtx::kNumCounters] = {0};
-        if (stats)
-            RTX_HIP(hipMemcpyAsync(c, sts[j]->d_counters, sizeof c, hipMemcpyDeviceToHost, sts[j]->stream));
-        RTX_HIP(hipStreamSynchronize(sts[j]->stream));
-        // scatter the packed tiles of this device into the frame (disjoint rows per device)
-        uint32_t ly = 0;
-        for (uint64_t t = static_cast<uint64_t>(j); t * tile_rows < H; t += static_cast<uint64_t>(n_devices)) {
-            const uint32_t r0 = static_cast<uint32_t>(t * tile_rows);
-            const uint32_t n = (H - r0 < tile_rows) ? H - r0 : tile_rows;
-            std::memcpy(out_rgb + r0 * row_bytes, sts[j]->h_stage + ly * row_bytes, n * row_bytes);
-            ly += n;
-        }
-        if (stats) {
-            float ms = 0.0f;
-            RTX_HIP(hipEventElapsedTime(&ms, sts[j]->ev0, sts[j]->ev1));
-            if (ms > kernel_ms) kernel_ms = ms;
-            for (int k = 0; k < rtx::kNumCounters; ++k) total[k] += c[k];
+        if (g.status() != hipSuccess) { g_last_hip_error = static_cast<int>(g.status()); return fail(RTX_ERR_HIP); }
+        const int rc = launch_on(scene, *sh.st, sh.spec, stats != nullptr);
+        if (rc != RTX_OK) return fail(rc);
+        launched.push_back(devices[j]);
+        hipError_t e = hipMemcpyAsync(sh.st->h_stage + sh.stage_offset, sh.st->d_out, sh.spec.local_rows * row_bytes,
+                                      hipMemcpyDeviceToHost, sh.st->stream);
+        if (e == hipSuccess && stats)   // a device's next share reuses its counter block: read this share's now (stream order)
+            e = hipMemcpyAsync(&counters[static_cast<size_t>(j) * rtx::kNumCounters], sh.st->d_counters,
+                               rtx::kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, sh.st->stream);
+        if (e != hipSuccess) { g_last_hip_error = static_cast<int>(e); return fail(e == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP); }
+        if (stats && unique.size() != static_cast<size_t>(n_devices)) {
+            // shares of one device run back to back and share its two timing events: take each share's time now
+            if ((e = hipStreamSynchronize(sh.st->stream)) != hipSuccess || (e = hipEventElapsedTime(&share_ms[j], sh.st->ev0, sh.st->ev1)) != hipSuccess) {
+                g_last_hip_error = static_cast<int>(e);
+                return fail(RTX_ERR_HIP);
+            }
         }
     }
-    if (stats) fill_stats(stats, scene, static_cast<uint64_t>(H) * W, total, kernel_ms, wall_ms() - t0);
+    double kernel_ms = 0.0;
+    for (auto &kv : unique) {
+        DeviceGuard g(kv.first);
+        if (g.status() != hipSuccess) { g_last_hip_error = static_cast<int>(g.status()); return fail(RTX_ERR_HIP); }
+        const hipError_t e = hipStreamSynchronize(kv.second->stream);
+        if (e != hipSuccess) { g_last_hip_error = static_cast<int>(e); return fail(RTX_ERR_HIP); }
+    }
+    for (int j = 0; j < n_devices; ++j) {
+        const Share &sh = shares[j];
+        if (!sh.spec.local_rows) continue;
+        // the packed tiles of this share go to their rows of the frame (disjoint rows per share)
+        rtxh_scatter_tiles(out_rgb, H, W, sh.st->h_stage + sh.stage_offset, static_cast<uint32_t>(j), static_cast<uint32_t>(n_devices), tile_rows);
+        if (stats) {
+            if (unique.size() == static_cast<size_t>(n_devices)) {
+                DeviceGuard g(devices[j]);
+                float ms = 0.0f;
+                if (g.status() == hipSuccess && hipEventElapsedTime(&ms, sh.st->ev0, sh.st->ev1) == hipSuccess) share_ms[j] = ms;
+            }
+            for (int k = 0; k < rtx::kNumCounters; ++k) total[k] += counters[static_cast<size_t>(j) * rtx::kNumCounters + k];
+        }
+    }
+    if (stats) {
+        // the frame's device time: the slowest device, a device's shares added up
+        std::map<DeviceState *, double> per_device;
+        for (int j = 0; j < n_devices; ++j) per_device[shares[j].st] += share_ms[j];
+        for (auto &kv : per_device) kernel_ms = std::max(kernel_ms, kv.second);
+        fill_stats(stats, scene, static_cast<uint64_t>(H) * W, total, kernel_ms, wall_ms() - t0);
+    }
     return RTX_OK;
 }
 
@@ -556,7 +632,7 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
     const size_t n = static_cast<size_t>(*tiles_x) * *tiles_y;
     if (!out) return RTX_OK;   // size query
     if (out_tiles < n) return RTX_ERR_BAD_ARG;
-    if ((rc = ensure_out(*st, static_cast<size_t>(nrows) * scene->prep.width * 3u, false)) != RTX_OK) return rc;
+    if ((rc = ensure_out(*st, static_cast<size_t>(nrows) * scene->prep.width * 3u, 0)) != RTX_OK) return rc;
     unsigned long long *d_prof = nullptr;
     const size_t prof_bytes = n * rtx::kWaveProfWords * sizeof(unsigned long long);
     RTX_HIP(hipMalloc(reinterpret_cast<void **>(&d_prof), prof_bytes));

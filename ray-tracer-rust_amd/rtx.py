@@ -115,6 +115,7 @@ _SIGS = {
     "rtxh_gen_samples": (None, [C.c_uint64, C.c_uint32, f32p]),
     "rtxh_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rtxh_synthetic_mesh": (C.c_int, [C.c_uint64, C.c_uint32, f32p]),
+    "rtxh_scatter_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(_lib, _name)
@@ -446,14 +447,21 @@ def tile_owner(tile, world_size):
 
 
 def scatter_tiles(frame, packed, first_tile, tile_stride, tile_rows):
-    """Place the packed rows of rtx_render_tiles_device back into a [H, W, 3] frame."""
-    h = frame.shape[0]
-    ly = 0
-    t = first_tile
-    while t * tile_rows < h:
-        r0 = t * tile_rows
-        n = min(tile_rows, h - r0)
-        frame[r0:r0 + n] = packed[ly:ly + n]
-        ly += n
-        t += tile_stride
+    """Place the packed rows of rtx_render_tiles_device back into a [H, W, 3] frame (rtxh_scatter_tiles: the loop
+    rtx_render_frame itself gathers with)."""
+    h, w = frame.shape[0], frame.shape[1]
+    assert frame.flags["C_CONTIGUOUS"] and frame.dtype == np.uint8
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    assert packed.size == tiles_rows_of(h, first_tile, tile_stride, tile_rows) * w * 3, "packed share has the wrong size"
+    _check(_lib.rtxh_scatter_tiles(frame.ctypes.data, h, w, packed.ctypes.data, first_tile, tile_stride, tile_rows),
+           "rtxh_scatter_tiles")
     return frame
+
+
+def tiles_rows_of(height, first_tile, tile_stride, tile_rows):
+    """Rows of the share (first_tile, tile_stride, tile_rows) of a frame of `height` rows."""
+    rows, t = 0, first_tile
+    while t * tile_rows < height:
+        rows += min(tile_rows, height - t * tile_rows)
+        t += tile_stride
+    return rows

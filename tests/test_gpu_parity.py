@@ -108,6 +108,26 @@ def test_rows_tiles_and_frames_are_identical(rtx, samples_seeded):
         assert e.value.code == rtx.ERR_NO_DEVICE
 
 
+def test_render_frame_with_several_shares_on_one_device(rtx, samples_seeded):
+    """rtx_render_frame's multi-share path (one share per entry of devices[]: launch everywhere, staged D2H, gather) on a
+    one-GPU box: device 0 named two, three and eight times.  Bytes and the summed counters must be those of the
+    one-share frame; device order in the array must not matter."""
+    W, H = 203, 117
+    with rtx.default_scene([model("big_bunny.obj")], W, H, samples_seeded) as s:
+        full, st1 = s.render_frame((0,), 8, stats=True)
+        assert np.array_equal(full, s.render_rows())
+        for devices, tile_rows in (((0, 0), 8), ((0, 0, 0), 5), ((0,) * 8, 16), ((0, 0), 200)):
+            img, st = s.render_frame(devices, tile_rows, stats=True)
+            assert np.array_equal(img, full), (devices, tile_rows)
+            for key in ("primary_rays", "primary_hits", "shadow_rays", "rays", "redo_tiles"):
+                assert st[key] == st1[key], (key, devices)
+            assert st["kernel_ms"] > 0.0
+            assert np.array_equal(s.render_frame(devices, tile_rows), full)      # without statistics too
+        with pytest.raises(rtx.RtxError) as e:
+            s.render_frame((0, 99), 8)
+        assert e.value.code == rtx.ERR_NO_DEVICE
+
+
 def test_device_resident_entry_point(rtx, samples_seeded):
     """rtx_render_tiles_device writes into caller-owned device memory on the caller's stream
     (torch tensor + torch stream: the bench.py plumbing)."""

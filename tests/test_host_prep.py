@@ -348,3 +348,39 @@ def test_global_triangles_sit_in_the_first_leaf(rtx, samples_half):
         info = s.info()
         nodes, order = s.nodes()
         assert info["n_global"] == 2 and info["n_nodes"] == 1 and int(nodes[0, 3]) == 2
+
+
+def test_scatter_tiles_places_every_share(rtx):
+    """rtxh_scatter_tiles — the gather loop of rtx_render_frame, factored out: for any frame height, tile height and
+    share count, scattering every share's packed rows rebuilds the frame, each row written exactly once."""
+    rng = np.random.default_rng(11)
+    for H, W, tile_rows, world in ((117, 5, 8, 3), (64, 3, 8, 8), (7, 2, 16, 2), (100, 4, 1, 7), (33, 1, 5, 1), (9, 2, 4, 6)):
+        full = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        frame = np.full_like(full, 0xEE)
+        written = np.zeros(H, np.int32)
+        for rank in range(world):
+            rows = [r for t in range(rank, (H + tile_rows - 1) // tile_rows, world)
+                    for r in range(t * tile_rows, min(H, (t + 1) * tile_rows))]
+            assert len(rows) == rtx.rtx.tiles_rows_of(H, rank, world, tile_rows)
+            packed = full[rows] if rows else np.zeros((0, W, 3), np.uint8)
+            rtx.scatter_tiles(frame, packed, rank, world, tile_rows)
+            written[rows] += 1
+        assert (written == 1).all() and np.array_equal(frame, full), (H, tile_rows, world)
+    lib = rtx.rtx._lib
+    buf = np.zeros((4, 4, 3), np.uint8)
+    assert lib.rtxh_scatter_tiles(None, 4, 4, buf.ctypes.data, 0, 1, 8) == rtx.ERR_BAD_ARG
+    assert lib.rtxh_scatter_tiles(buf.ctypes.data, 4, 4, buf.ctypes.data, 0, 0, 8) == rtx.ERR_BAD_ARG
+    assert lib.rtxh_scatter_tiles(buf.ctypes.data, 4, 4, buf.ctypes.data, 0, 1, 0) == rtx.ERR_BAD_ARG
+
+
+def test_render_frame_rejects_row_numbers_beyond_32_bits(rtx, samples_half):
+    """n_devices x tile_rows is a 32-bit row stride inside the kernels: rtx_render_frame refuses what would wrap
+    (before it looks at any device, so this runs on a CPU-only box)."""
+    import ctypes as C
+    with rtx.default_scene([model("bunny.obj")], 16, 16, samples_half[:64]) as s:
+        out = np.zeros((16, 16, 3), np.uint8)
+        devs = (C.c_int * 2)(0, 1)
+        rc = rtx.rtx._lib.rtx_render_frame(s.handle, devs, 2, 0x80000000, out.ctypes.data, None)
+        assert rc == rtx.ERR_BAD_ARG
+        rc = rtx.rtx._lib.rtx_render_frame(s.handle, devs, 0, 8, out.ctypes.data, None)
+        assert rc == rtx.ERR_BAD_ARG
