@@ -95,7 +95,10 @@ constexpr uint32_t kStreamCtrWords = 4u;   // counters of the streamed (ablation
 constexpr int kNumCounters = 8;
 
 // Light samples per LDS batch (results of one batch: 64 pixels x batch floats).
-constexpr uint32_t kMaxLightBatch = 128u;
+#ifndef RTX_LIGHT_BATCH
+#define RTX_LIGHT_BATCH 128
+#endif
+constexpr uint32_t kMaxLightBatch = RTX_LIGHT_BATCH;
 
 // Kernel variants, kept selectable (RTX_VARIANT) so that profiles can show what each choice is worth:
 // bit 0 = conservative multiply-based box test for inner nodes (else the exact division-based one);

@@ -158,16 +158,23 @@ __device__ __forceinline__ void shadow_result_grey(const float *__restrict__ l_h
     const LaneRay &r = s.ray;
     const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
     const bool lit = r.best_idx == kNone;
-    if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? (h[6] * lnd) / denom : kOccluded;
+    // an occluded sample contributes (black * 1.0) / denom = +0.0 (main.rs:226): adding it changes no sum of this kind
+    // (they start at +0.0 and only grow), so the ordered accumulation needs no test
+    if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? (h[6] * lnd) / denom : 0.0f;
 }
 
+__device__ __forceinline__ void store_pixel(const DeviceScene &S, const float *__restrict__ thr, uint8_t *__restrict__ out,
+                                            uint32_t px, uint32_t ly, float r, float g, float b)
+{
+    uint8_t *p = out + ((size_t)ly * S.width + px) * 3u;                             // put_pixel, main.rs:293-294
+    p[0] = (uint8_t)quantise(thr, r);
+    p[1] = (uint8_t)quantise(thr, g);
+    p[2] = (uint8_t)quantise(thr, b);
+}
 __device__ __forceinline__ void store_pixel(const DeviceScene &S, uint8_t *__restrict__ out, uint32_t px, uint32_t ly,
                                             float r, float g, float b)
 {
-    uint8_t *p = out + ((size_t)ly * S.width + px) * 3u;                             // put_pixel, main.rs:293-294
-    p[0] = (uint8_t)quantise(S.gamma_thr, r);
-    p[1] = (uint8_t)quantise(S.gamma_thr, g);
-    p[2] = (uint8_t)quantise(S.gamma_thr, b);
+    store_pixel(S, S.gamma_thr, out, px, ly, r, g, b);
 }
 
 template <bool COUNT>
@@ -189,7 +196,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long *__restrict__ 
 __host__ __device__ inline uint32_t lds_res_stride(uint32_t batch) { return batch | 1u; }   // odd: conflict-free column reads
 __host__ __device__ inline uint32_t lds_floats(uint32_t batch)
 {
-    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u + 2u * kMaxCut;
+    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u + 2u * kMaxCut + 256u;
 }
 
 
@@ -788,6 +795,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     float *const l_pix = l_res + 64u * res_stride;                                    // per pixel: running sums r,g,b + hit slot
     uint32_t *const l_ctl = reinterpret_cast<uint32_t *>(l_pix + 64u * 4u);           // [1] redo flag, [3] tile
     uint32_t *const l_cut = l_ctl + 4u;                                                // the tile's cut: (begin, end) pairs
+    float *const l_thr = reinterpret_cast<float *>(l_cut + 2u * kMaxCut);               // the 256 gamma thresholds (eight dependent
+    for (uint32_t k = threadIdx.x; k < 256u; k += 64u * NW) l_thr[k] = S.gamma_thr[k];   // reads per channel per pixel: LDS, not L1)
 
 #if RTX_WIDE_WALK
     const WideNode RTX_CONSTANT *wide = (const WideNode RTX_CONSTANT *)S.wide;
@@ -818,11 +827,22 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     uint32_t tl_tile = kNone;   // tile's spare word by the work-item that claims the jobs
     unsigned long long tl_t0 = 0;
 #endif
+    // The next job is claimed by the work-item that claims them while the current job's LAST phase runs (the ordered sums
+    // of its last batch: one wavefront working, seven waiting), so that the claim's latency — an atomic's round trip, then
+    // a load that depends on it — does not stand between two jobs, and as late as that so that the list stays a dynamic
+    // one.  (Claiming two jobs ahead at the top of a job tied the costliest jobs, which come first, to workgroups three
+    // at a time: +17 % on a 1080p frame.)
+    const uint32_t n_jobs = W.buckets[0];
+    uint32_t job_ahead = kNone;
+    bool have_ahead = false;
     for (;;) {
         if (threadIdx.x == 0) {
-            // q-th job, costliest class first
-            const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
-            l_ctl[3] = q < W.buckets[0] ? W.buckets[3u * kCostBuckets + q] : kNone;
+            if (!have_ahead) {   // the first job, and after jobs without a last phase
+                const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);            // q-th job, costliest class first
+                job_ahead = q < n_jobs ? W.buckets[3u * kCostBuckets + q] : kNone;
+            }
+            l_ctl[3] = job_ahead;
+            have_ahead = false;
             l_ctl[1] = 0u;
 #if RTX_EXPERIMENT_TIMELINE
             const unsigned long long now = wall_clock64();
@@ -921,6 +941,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 #else
                     if (wave == 0) {
 #endif
+                        if (threadIdx.x == 0 && b0 + batch >= S.nb_light) {          // last batch: claim the next job now
+                            const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
+                            job_ahead = q < n_jobs ? W.buckets[3u * kCostBuckets + q] : kNone;
+                            have_ahead = true;
+                        }
                         const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
                         const bool hit = slot < 64u;
                         float acc_r = l_pix[4u * lane], acc_g = l_pix[4u * lane + 1u], acc_b = l_pix[4u * lane + 2u];
@@ -929,10 +954,17 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         if (hit) {
                             const float *res = l_res + slot * res_stride;
                             if (grey_tile) {
-                                for (uint32_t i = 0; i < bc; ++i) {                   // i ascending, main.rs:209-216
-                                    const float q = res[i];                           // (color.red * lnd) / denom, or the marker
-                                    if (!(q < 0.0f)) acc_r = acc_r + q;
+                                // i ascending, main.rs:209-216: res[i] = (color.red * lnd) / denom, +0.0 when occluded.  Eight
+                                // reads in flight per step: this chain of additions is what one wavefront does alone
+                                // while seven wait
+                                uint32_t i = 0;
+                                for (; i + 8u <= bc; i += 8u) {
+                                    const float q0 = res[i], q1 = res[i + 1u], q2 = res[i + 2u], q3 = res[i + 3u];
+                                    const float q4 = res[i + 4u], q5 = res[i + 5u], q6 = res[i + 6u], q7 = res[i + 7u];
+                                    acc_r = acc_r + q0; acc_r = acc_r + q1; acc_r = acc_r + q2; acc_r = acc_r + q3;
+                                    acc_r = acc_r + q4; acc_r = acc_r + q5; acc_r = acc_r + q6; acc_r = acc_r + q7;
                                 }
+                                for (; i < bc; ++i) acc_r = acc_r + res[i];
                                 acc_g = acc_r;
                                 acc_b = acc_r;
                             } else {
@@ -971,7 +1003,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 } else {
                     uint32_t px, py, ly;
                     if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly) && mine)
-                        store_pixel(S, out, px, ly, l_pix[4u * lane], l_pix[4u * lane + 1u], l_pix[4u * lane + 2u]);
+                        store_pixel(S, l_thr, out, px, ly, l_pix[4u * lane], l_pix[4u * lane + 1u], l_pix[4u * lane + 2u]);
                 }
             }
         }
@@ -1003,7 +1035,10 @@ template <bool COUNT, bool FAST, bool SPHERES>
 hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out, uint32_t *d_redo,
                         const StreamWorkspace &W, unsigned long long *d_counters, hipStream_t stream, hipEvent_t *ev)
 {
-    constexpr int NW = 8;
+#ifndef RTX_SHADE_NW
+#define RTX_SHADE_NW 8
+#endif
+    constexpr int NW = RTX_SHADE_NW;     // wavefronts per workgroup of shade_tiles_kernel
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
     const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
