@@ -131,7 +131,7 @@ __device__ __forceinline__ ShadowRay shadow_ray_at(const float *__restrict__ l_h
     const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;                   // p - orig
     float dist_light, sx, sy, sz;
     length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);                         // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
-    s.ray = make_ray(valid, hx, hy, hz, sx, sy, sz);
+    s.ray = make_ray_bare(valid, hx, hy, hz, sx, sy, sz);     // the caller adds the culling constants when the ray walks
     s.ray.limit = dist_light;
     s.valid = valid;
     return s;
@@ -781,7 +781,11 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 #define RTX_SHADE_WAVES_PER_SIMD 8
 #endif
 
-template <bool COUNT, bool FAST, int NW, bool SPHERES>
+// WHOLE: the scene is too large for per-tile cuts (probe_kernel: kCutMaxNodes) and every chunk walks the whole stream —
+// a kernel of its own, so that neither form carries the other's registers: the whole-stream loop is three scalar
+// instructions per record shorter than the loop over a cut's ranges (9 % of a frame of the 1M-triangle soup), and the
+// cut form has a path for chunks with nothing to walk.
+template <bool COUNT, bool FAST, int NW, bool SPHERES, bool WHOLE>
 __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_SHADE_WAVES_PER_SIMD)
 shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x, uint32_t n_tiles, uint32_t r,
                    StreamWorkspace W, uint8_t *__restrict__ out, uint32_t *__restrict__ queue,
@@ -818,7 +822,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveCounters wc;
 #if !RTX_WIDE_WALK
-    const bool whole_tree = S.n_nodes > kCutMaxNodes;
+    constexpr bool whole_tree = WHOLE;
 #endif
     const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
     static_assert(sizeof(HitRec) == kHitStride * sizeof(float), "the LDS hit record is the HBM hit record");
@@ -915,20 +919,28 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         const bool no_ground = have_plane &&
                             (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
+                        // A chunk with nothing to walk — no subtree in the tile's cut, and the ground (the only global triangle)
+                        // ruled out from its plane — is lit; what is left of the walk's own prologue is its refusal of hard
+                        // directions (closest_hit: such a tile is re-rendered against the reference's tree).  Three of four
+                        // chunks of a frame of the default scene are of this kind.
+                        bool ok;
 #if RTX_EXPERIMENT_NO_WALK      // timing experiment only (wrong pixels): what a frame costs without any walk
-                        const bool ok = true;
+                        ok = true;
                         (void)no_ground;
+#elif RTX_WIDE_WALK
+                        ray_cull_constants(sr.ray);
+                        ok = hit_wide<COUNT, FAST, SPHERES, true>(wide, S.n_wide, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
 #else
-#if RTX_WIDE_WALK
-                        const bool ok = hit_wide<COUNT, FAST, SPHERES, true>(wide, S.n_wide, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
-#else
-                        // main.rs:204.  Scenes too large for per-tile cuts (probe_kernel: kCutMaxNodes) walk the whole
-                        // stream: that loop is three scalar instructions per record shorter than the loop over a cut's
-                        // ranges, which is worth 9 % of a frame of the 1M-triangle soup
-                        const bool ok = whole_tree
-                            ? any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground)
-                            : any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);
-#endif
+                        const bool nothing_to_walk = n_cut == 0u && !whole_tree && (S.n_global == 0u || (S.n_global == 1u && no_ground));
+                        if (nothing_to_walk) {
+                            ok = ballot(sr.ray.active && direction_is_hard(sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull;
+                        } else {
+                            ray_cull_constants(sr.ray);                              // main.rs:204
+                            if (whole_tree)
+                                ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);
+                            else
+                                ok = any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);
+                        }
 #endif
                         if (!ok && lane == 0) l_ctl[1] = 1u;
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
@@ -1039,6 +1051,11 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
 #define RTX_SHADE_NW 8
 #endif
     constexpr int NW = RTX_SHADE_NW;     // wavefronts per workgroup of shade_tiles_kernel
+#if RTX_WIDE_WALK
+    const bool whole = false;
+#else
+    const bool whole = S.n_nodes > kCutMaxNodes;
+#endif
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
     const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
@@ -1050,7 +1067,7 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     if (e != hipSuccess) return e;
     if (dev != cached_dev || lds_bytes != cached_lds) {
         int per_cu = 0, cus = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_tiles_kernel<COUNT, FAST, NW, SPHERES>, 64 * NW, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_tiles_kernel<COUNT, FAST, NW, SPHERES, false>, 64 * NW, lds_bytes);
         if (e != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         cached_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
@@ -1070,8 +1087,12 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
         hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
         hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W, grid, split_share());
         if (ev && r == 0u && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;   // end of the scheduling pass
-        hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
-                           batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
+        if (whole)
+            hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES, true>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
+                               batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
+        else
+            hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES, false>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
+                               batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL((reference_tiles_kernel<COUNT, SPHERES>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream,

@@ -299,23 +299,37 @@ __device__ __forceinline__ bool candidate_occludes(const LaneRay &r, float t)
     return !(sqrtf(qx * qx + qy * qy + qz * qz) > r.limit);                                                     // main.rs:221
 }
 
-__device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, float oz, float dx, float dy, float dz)
+// origin, direction and the result fields; the constants of the multiply-based culling are added by ray_cull_constants
+// (a chunk that has nothing to walk never needs them)
+__device__ __forceinline__ LaneRay make_ray_bare(bool active, float ox, float oy, float oz, float dx, float dy, float dz)
 {
     LaneRay r;
     r.ox = ox; r.oy = oy; r.oz = oz;
     r.dx = dx; r.dy = dy; r.dz = dz;
-    // Culling only: v_rcp_f32 (1 ulp, e_r <= 2^-23 instead of 2^-24) replaces the ten-instruction IEEE division.
-    // The bound of slab_fast_fma becomes 5*2^-24 |t| + 1.01*2^-24 |o/d|, still three times inside its widening
-    // (slab_fast: 6*2^-24 against 16*2^-24).  Regular directions only reach these values: 2^-60 <= |d| <= 2.
-    r.ix = __builtin_amdgcn_rcpf(dx); r.iy = __builtin_amdgcn_rcpf(dy); r.iz = __builtin_amdgcn_rcpf(dz);
-    const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
-    r.nx = -px; r.ny = -py; r.nz = -pz;
-    r.slack0 = __builtin_fmaf(fabsf(px) + fabsf(py) + fabsf(pz), 0x1p-21f, 0x1p-100f);
-    r.behind = -1.00001f * r.slack0;
+    r.ix = r.iy = r.iz = r.nx = r.ny = r.nz = r.slack0 = r.behind = 0.0f;
     r.best_t = __builtin_inff();
     r.best_idx = kNone;
     r.active = active;
     r.limit = __builtin_inff();
+    return r;
+}
+
+__device__ __forceinline__ void ray_cull_constants(LaneRay &r)
+{
+    // Culling only: v_rcp_f32 (1 ulp, e_r <= 2^-23 instead of 2^-24) replaces the ten-instruction IEEE division.
+    // The bound of slab_fast_fma becomes 5*2^-24 |t| + 1.01*2^-24 |o/d|, still three times inside its widening
+    // (slab_fast: 6*2^-24 against 16*2^-24).  Regular directions only reach these values: 2^-60 <= |d| <= 2.
+    r.ix = __builtin_amdgcn_rcpf(r.dx); r.iy = __builtin_amdgcn_rcpf(r.dy); r.iz = __builtin_amdgcn_rcpf(r.dz);
+    const float px = r.ox * r.ix, py = r.oy * r.iy, pz = r.oz * r.iz;
+    r.nx = -px; r.ny = -py; r.nz = -pz;
+    r.slack0 = __builtin_fmaf(fabsf(px) + fabsf(py) + fabsf(pz), 0x1p-21f, 0x1p-100f);
+    r.behind = -1.00001f * r.slack0;
+}
+
+__device__ __forceinline__ LaneRay make_ray(bool active, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    LaneRay r = make_ray_bare(active, ox, oy, oz, dx, dy, dz);
+    ray_cull_constants(r);
     return r;
 }
 
