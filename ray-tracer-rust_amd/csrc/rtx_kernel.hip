@@ -785,8 +785,15 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 // a kernel of its own, so that neither form carries the other's registers: the whole-stream loop is three scalar
 // instructions per record shorter than the loop over a cut's ranges (9 % of a frame of the 1M-triangle soup), and the
 // cut form has a path for chunks with nothing to walk.
+// Wavefronts per SIMD the register allocation must allow: the whole-stream form lives on resident wavefronts (its walks
+// are long chains of dependent scalar loads: 8, i.e. 64 vector and 78 scalar registers; at 6 the 1M-triangle soup takes
+// 20 % longer); the cut form, whose frames are mostly chunks that walk little or nothing, does better with the registers
+// of 6 (fewer scalar registers spilled to lanes: -3 % on big_bunny 4096x4096, -7 % on the ground-only frame, 1080p equal).
+#ifndef RTX_SHADE_CUT_WAVES_PER_SIMD
+#define RTX_SHADE_CUT_WAVES_PER_SIMD 6
+#endif
 template <bool COUNT, bool FAST, int NW, bool SPHERES, bool WHOLE>
-__global__ void __launch_bounds__(64 * NW, COUNT ? 1 : RTX_SHADE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64 * NW, COUNT ? 1 : (WHOLE ? RTX_SHADE_WAVES_PER_SIMD : RTX_SHADE_CUT_WAVES_PER_SIMD))
 shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x, uint32_t n_tiles, uint32_t r,
                    StreamWorkspace W, uint8_t *__restrict__ out, uint32_t *__restrict__ queue,
                    unsigned long long *__restrict__ counters)
@@ -1060,19 +1067,23 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
     const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
     const uint32_t n_tiles = tiles_x * tiles_y;
+    // persistent grid = what the device keeps resident of the form that is launched (the two forms differ in registers)
     static thread_local int cached_dev = -1, cached_blocks = 0;
     static thread_local size_t cached_lds = 0;
+    static thread_local bool cached_whole = false;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev != cached_dev || lds_bytes != cached_lds) {
+    if (dev != cached_dev || lds_bytes != cached_lds || whole != cached_whole) {
         int per_cu = 0, cus = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_tiles_kernel<COUNT, FAST, NW, SPHERES, false>, 64 * NW, lds_bytes);
+        e = whole ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_tiles_kernel<COUNT, FAST, NW, SPHERES, true>, 64 * NW, lds_bytes)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_tiles_kernel<COUNT, FAST, NW, SPHERES, false>, 64 * NW, lds_bytes);
         if (e != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         cached_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
         cached_dev = dev;
         cached_lds = lds_bytes;
+        cached_whole = whole;
     }
     if (n_tiles > kJobTileMask) return hipErrorInvalidValue;
     const uint64_t most_jobs = (uint64_t)n_tiles * kMaxTileParts;
