@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     if (lane == 0) {
         const bool count_it = !(flags & 2u);
         const uint32_t key = (sky || (flags & 2u)) ? kNone : cost_class(cost);
-#if RTX_EXPERIMENT_TIMELINE
+#if RTX_EXPERIMENT_TIMELINE || RTX_EXPERIMENT_PHASES
         W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), 0u};   // spare word: the tile's jobs add their durations
 #else
         W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), counted + (count_it ? n_hit : 0u)};
@@ -789,6 +789,9 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 // are long chains of dependent scalar loads: 8, i.e. 64 vector and 78 scalar registers; at 6 the 1M-triangle soup takes
 // 20 % longer); the cut form, whose frames are mostly chunks that walk little or nothing, does better with the registers
 // of 6 (fewer scalar registers spilled to lanes: -3 % on big_bunny 4096x4096, -7 % on the ground-only frame, 1080p equal).
+#ifndef RTX_SHADE_PRIORITY
+#define RTX_SHADE_PRIORITY 1
+#endif
 #ifndef RTX_SHADE_CUT_WAVES_PER_SIMD
 #define RTX_SHADE_CUT_WAVES_PER_SIMD 6
 #endif
@@ -838,14 +841,19 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     uint32_t tl_tile = kNone;   // tile's spare word by the work-item that claims the jobs
     unsigned long long tl_t0 = 0;
 #endif
-    // The next job is claimed by the work-item that claims them while the current job's LAST phase runs (the ordered sums
-    // of its last batch: one wavefront working, seven waiting), so that the claim's latency — an atomic's round trip, then
-    // a load that depends on it — does not stand between two jobs, and as late as that so that the list stays a dynamic
-    // one.  (Claiming two jobs ahead at the top of a job tied the costliest jobs, which come first, to workgroups three
+    // The next job is claimed by the work-item that claims them while the current job's last batch runs (its position in
+    // the list is requested when the batch's rays start, turned into a job id when its ordered sums start), so that the
+    // claim's latency — an atomic's round trip, then a load that depends on it — does not stand between two jobs, and no
+    // earlier than that so that the list stays a dynamic one.  (Claiming two jobs ahead at the top of a job tied the costliest jobs, which come first, to workgroups three
     // at a time: +17 % on a 1080p frame.)
     const uint32_t n_jobs = W.buckets[0];
-    uint32_t job_ahead = kNone;
+    uint32_t job_ahead = kNone, q_ahead = 0u;
     bool have_ahead = false;
+    // the light points are the same for every job of a launch (main.rs:194-196: sample i of primary ray r): when one batch
+    // holds them all they are staged once, not once per job (a global round trip of 2.4 us in front of every job's rays)
+    const bool lights_once = S.nb_light <= batch;
+    if (lights_once)
+        for (uint32_t k = threadIdx.x; k < 3u * S.nb_light; k += 64u * NW) l_light[k] = S.light_points[3u * (r * S.nb_light) + k];
     for (;;) {
         if (threadIdx.x == 0) {
             if (!have_ahead) {   // the first job, and after jobs without a last phase
@@ -865,10 +873,33 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         __syncthreads();
         const uint32_t job = __builtin_amdgcn_readfirstlane(l_ctl[3]);
         if (job == kNone) break;
+#if RTX_SHADE_PRIORITY
+        // A job's short serial stretches (its loads into LDS, the ordered sums, the store) are what the other wavefronts
+        // of its workgroup wait for at barriers: they issue ahead of the other workgroups' ray loops on the same SIMD
+        __builtin_amdgcn_s_setprio(RTX_SHADE_PRIORITY);
+#endif
+#if RTX_EXPERIMENT_PHASES       // timing experiment only: where a job of a tile with an empty cut spends its time (100 MHz ticks)
+        unsigned long long ph_t[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
+#endif
         // part `part` of 2^parts_log of the tile: its hit records [h0, h0 + n_hit), the pixels they belong to, and (part 0)
         // the tile's pixels without a hit
         const uint32_t tile_id = job & kJobTileMask, part = (job >> kJobTileBits) & 15u, parts_log = job >> kJobPartsShift;
         const uint32_t tile_x = tile_id % tiles_x, tile_y = tile_id / tiles_x;
+        // A whole tile's job requests everything it needs from HBM at once — the tile's descriptor, all 64 of its hit-record
+        // slots, its pixel slots, its cut list — and sorts it out when it is there: waiting for the descriptor first, to ask
+        // only for the records that exist, made two dependent round trips in front of every such job.  A PART of a tile
+        // (costly tiles only) keeps the two steps: sixteen parts would each fetch the whole tile's records.
+        const float *tile_hits = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u);
+        float hit_words[(64u * kHitStride + 64u * NW - 1u) / (64u * NW)];
+        if (parts_log == 0u) {
+#pragma unroll
+            for (uint32_t j = 0; j < sizeof(hit_words) / sizeof(float); ++j) {
+                const uint32_t k = threadIdx.x + j * 64u * NW;
+                hit_words[j] = k < 64u * kHitStride ? tile_hits[k] : 0.0f;
+            }
+        }
+        const uint32_t cut_word = threadIdx.x < 2u * kMaxCut ? reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x] : 0u;
+        const uint32_t pix_word = wave == 0u ? W.pix_slot[(size_t)tile_id * 64u + lane] : kNone;   // (with the rest: not behind the descriptor)
         const TileDesc td = W.tiles[tile_id];
         const uint32_t n_all = __builtin_amdgcn_readfirstlane(td.n_hit);
         const uint32_t h0 = (part * n_all) >> parts_log;
@@ -878,21 +909,30 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         const bool skip = (tflags & 2u) != 0u;      // already queued for the reference re-render
         const uint32_t n_cut = (tflags >> kTileCutShift) & 0xFFu;
         if (!skip) {
-            const float *src = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u + h0);
-            for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = src[k];
-            if (threadIdx.x < 2u * n_cut)
-                l_cut[threadIdx.x] = reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x];
+            if (parts_log == 0u) {
+#pragma unroll
+                for (uint32_t j = 0; j < sizeof(hit_words) / sizeof(float); ++j) {
+                    const uint32_t k = threadIdx.x + j * 64u * NW;
+                    if (k < n_hit * kHitStride) l_hit[k] = hit_words[j];
+                }
+            } else {                                                                 // the part's records [h0, h0 + n_hit) -> LDS [0, n_hit)
+                for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = tile_hits[h0 * kHitStride + k];
+            }
+            if (threadIdx.x < 2u * n_cut) l_cut[threadIdx.x] = cut_word;
             if (wave == 0) {
                 const size_t pix = (size_t)tile_id * 64u + lane;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                               // main.rs:182
                 if (r != 0u) { a0 = W.acc[3u * pix]; a1 = W.acc[3u * pix + 1u]; a2 = W.acc[3u * pix + 2u]; }
                 l_pix[4u * lane] = a0; l_pix[4u * lane + 1u] = a1; l_pix[4u * lane + 2u] = a2;
                 // the pixel's hit record within this part; kNone: no hit and the pixel is this part's; kNotMine: another part's
-                const uint32_t g = W.pix_slot[pix];
+                const uint32_t g = pix_word;
                 reinterpret_cast<uint32_t *>(l_pix)[4u * lane + 3u] =
                     g == kNone ? (part == 0u ? kNone : kNotMine) : (g - h0 < n_hit ? g - h0 : kNotMine);
             }
             __syncthreads();
+#if RTX_EXPERIMENT_PHASES
+            ph_t[1] = wall_clock64();
+#endif
             if (wave == 0) {   // grey tile (every BASELINE scene): the three channel sums are the same f32 sequence
                 const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
                 const bool hit = slot < 64u;
@@ -905,9 +945,20 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             if (n_hit != 0u) {                                                        // else main.rs:235
                 for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                 // main.rs:193, in batches that fit LDS
                     const uint32_t bc = (S.nb_light - b0 < batch) ? S.nb_light - b0 : batch;
-                    for (uint32_t k = threadIdx.x; k < 3u * bc; k += 64u * NW)
-                        l_light[k] = S.light_points[3u * (r * S.nb_light + b0) + k]; // main.rs:194-196 (hoisted to the host)
-                    __syncthreads();
+                    if (!lights_once) {
+                        for (uint32_t k = threadIdx.x; k < 3u * bc; k += 64u * NW)
+                            l_light[k] = S.light_points[3u * (r * S.nb_light + b0) + k]; // main.rs:194-196 (hoisted to the host)
+                    }
+                    __syncthreads();   // (also publishes the grey flag)
+                    // A tile with an empty cut is through its rays in 10 us: the next job's position in the list is requested
+                    // now, by the work-item that claims the jobs, and turned into a job id when the ordered sums start —
+                    // neither round trip is waited for.  (A costly job claims when its sums start: claimed a hundred
+                    // microseconds ahead, the costliest jobs are tied to workgroups two at a time, +13 % on a 1080p frame.)
+                    const bool claim_early = n_cut == 0u;
+                    if (threadIdx.x == 0 && b0 + batch >= S.nb_light && claim_early) q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
+#if RTX_EXPERIMENT_PHASES
+                    ph_t[2] = wall_clock64();
+#endif
                     // phase 2: shadow rays, one work-item per (hit pixel, sample)
                     const uint32_t total = n_hit * bc;
                     const uint32_t div = sample_major ? n_hit : bc;
@@ -919,6 +970,9 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // it from the next integer (checked exhaustively for the domain, ray < 8320, div <= 128).  The
                     // general 32-bit division costs three quarter-rate multiplies and a dozen more instructions.
                     const float inv_div = 1.0f / (float)div;
+#if RTX_SHADE_PRIORITY
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
                         const bool valid = c0 + lane < total;
                         const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
@@ -953,16 +1007,22 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
                         else shadow_result(l_hit, l_res, res_stride, sr);
                     }
+#if RTX_SHADE_PRIORITY
+                    __builtin_amdgcn_s_setprio(RTX_SHADE_PRIORITY);
+#endif
                     __syncthreads();
+#if RTX_EXPERIMENT_PHASES
+                    ph_t[3] = wall_clock64();
+#endif
                     // phase 3: ordered accumulation, one work-item per pixel (wave 0)
 #if RTX_EXPERIMENT_NO_SUM       // timing experiment only (wrong pixels): what a frame costs without the ordered sums
                     if (false) {
 #else
                     if (wave == 0) {
 #endif
-                        if (threadIdx.x == 0 && b0 + batch >= S.nb_light) {          // last batch: claim the next job now
-                            const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);
-                            job_ahead = q < n_jobs ? W.buckets[3u * kCostBuckets + q] : kNone;
+                        if (threadIdx.x == 0 && b0 + batch >= S.nb_light) {          // last batch: the claimed position -> job id
+                            if (!claim_early) q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
+                            job_ahead = q_ahead < n_jobs ? W.buckets[3u * kCostBuckets + q_ahead] : kNone;
                             have_ahead = true;
                         }
                         const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
@@ -1000,6 +1060,9 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
                     }
                     __syncthreads();   // results and light points are overwritten by the next batch
+#if RTX_EXPERIMENT_PHASES
+                    ph_t[4] = wall_clock64();
+#endif
                 }
             }
             if (wave == 0) {
@@ -1027,6 +1090,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             }
         }
         __syncthreads();   // the control words and hit records are rewritten by the next tile
+#if RTX_EXPERIMENT_PHASES
+        ph_t[5] = wall_clock64();
+        if (threadIdx.x == 0 && n_cut == 0u && n_hit != 0u && !skip) {   // totals in the spare words of the first tiles' descriptors
+            for (int k = 0; k < 5; ++k) atomicAdd(&W.tiles[k].pad, (uint32_t)(ph_t[k + 1] - ph_t[k]));
+            atomicAdd(&W.tiles[5].pad, 1u);
+        }
+#endif
     }
     if (COUNT && lane == 0) flush_counters<COUNT>(counters, 0ull, wc);
 }

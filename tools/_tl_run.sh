@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/_tl_run.sh <workload>   (timeline experiment build + run, with a watchdog that prints where python hangs)
 cd "$(dirname "$0")/.."
-make -s -C ray-tracer-rust_amd/csrc clean && make -s -j4 -C ray-tracer-rust_amd/csrc all EXTRA=-DRTX_EXPERIMENT_TIMELINE=1 > gpurun_out/r2_tl_build.log 2>&1
+make -s -C ray-tracer-rust_amd/csrc clean && make -s -j4 -C ray-tracer-rust_amd/csrc all EXTRA="${TL_FLAGS:--DRTX_EXPERIMENT_TIMELINE=1}" > gpurun_out/r2_tl_build.log 2>&1
 for wl in "$@"; do
 timeout -k 5 150 python -u -c "
 import faulthandler, sys; faulthandler.dump_traceback_later(90, exit=True)
