@@ -62,6 +62,15 @@ struct HitRec {          // 48 B
     float p[3], n[3], rgb[3], pad[3];
 };
 static_assert(sizeof(TileDesc) == 16 && sizeof(HitRec) == 48, "stream record sizes");
+// One entry of a tile's cut: the record range [begin, end) of the node stream that holds a subtree (wide build: begin =
+// byte offset of a wide node), and a copy of the subtree's ROOT record — a chunk tests the roots of its tile's cut out
+// of LDS and fetches from the stream only below a root it passes.
+struct CutEntry {
+    uint32_t begin, end;
+    NodeDev  root;
+};
+static_assert(sizeof(CutEntry) == 40, "CutEntry is ten dwords");
+constexpr uint32_t kCutWords = sizeof(CutEntry) / 4u;
 struct StreamWorkspace {
     HitRec   *hits;      // one per primary hit, compacted per tile
     uint32_t *pix_slot;  // tiles x 64: hit record of the pixel, or 0xFFFFFFFF
@@ -71,9 +80,8 @@ struct StreamWorkspace {
     float    *acc;       // tiles x 64 x 3 running sums, only when nb_ray > 1
     uint32_t *ctr;       // hit count, chunk count, chunk cursor
     uint32_t *buckets;   // probe pipeline: tile order by cost class (layout: order_tiles_kernel)
-    uint2    *cut;       // tiles x kMaxCut: the subtrees (record ranges [x, y) of the node stream; wide build: x = byte offset of
-                         // a wide node) the tile's shaft towards the light can touch — written by probe_kernel, walked
-                         // by shade_tiles_kernel
+    CutEntry *cut;       // tiles x kMaxCut: the subtrees the tile's shaft towards the light can touch — written by
+                         // probe_kernel, walked by shade_tiles_kernel
 };
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets, cut; };
 #ifndef RTX_MAX_CUT

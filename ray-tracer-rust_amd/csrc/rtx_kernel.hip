@@ -196,7 +196,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long *__restrict__ 
 __host__ __device__ inline uint32_t lds_res_stride(uint32_t batch) { return batch | 1u; }   // odd: conflict-free column reads
 __host__ __device__ inline uint32_t lds_floats(uint32_t batch)
 {
-    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u + 2u * kMaxCut + 256u;
+    return 3u * batch + 64u * kHitStride + 64u * lds_res_stride(batch) + 64u * 4u + 4u + kCutWords * kMaxCut + 256u;
 }
 
 
@@ -400,7 +400,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // Returns the number of entries written to `out` (byte offsets of wide nodes); *weight = a proxy of what one chunk's
 // walk of the cut will fetch.
 __device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ wide, const Shaft &sh,
-                                                   uint2 *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
+                                                   CutEntry *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
                                                    uint32_t &weight)
 {
     uint32_t my = 0u, my_size = 0u, n_front = 1u, n_out = 0u, w = 0u;
@@ -438,14 +438,14 @@ __device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ 
         const uint32_t n_entry = (uint32_t)__popcll(m_entry);
         if (n_out + n_entry + total > kMaxCut) {      // stop here: the live nodes of this level are the rest of the cut
             if (live) {
-                out[n_out + (uint32_t)__popcll(m_live & below)] = make_uint2(my, 0u);
+                out[n_out + (uint32_t)__popcll(m_live & below)] = CutEntry{my, 0u, NodeDev{}};
                 w += 4u + 6u * (32u - (uint32_t)__clz((int)my_size));
             }
             n_out += (uint32_t)__popcll(m_live);
             break;
         }
         if (with_leaf) {
-            out[n_out + (uint32_t)__popcll(m_entry & below)] = make_uint2(my, 0u);
+            out[n_out + (uint32_t)__popcll(m_entry & below)] = CutEntry{my, 0u, NodeDev{}};
             w += 4u + 6u * (32u - (uint32_t)__clz((int)my_size));
         }
         n_out += n_entry;
@@ -477,7 +477,7 @@ __device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ 
 // node's two children (the next record, and the one its `info` names) join the next frontier.  Entries are record
 // ranges [begin, end) of the stream.
 __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__ nodes, uint32_t root, const Shaft &sh,
-                                                     uint2 *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
+                                                     CutEntry *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
                                                      uint32_t &weight)
 {
     uint32_t my = root, n_front = 1u, n_out = 0u, w = 0u;
@@ -492,7 +492,7 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         const unsigned long long below = (1ull << lane) - 1ull;
         if (n_out + n_leaf + 2u * n_exp > kMaxCut) {      // stop here: the passing nodes of this level are the rest of the cut
             if (pass) {
-                out[n_out + (uint32_t)__popcll(m_pass & below)] = make_uint2(my, leaf ? my + 1u : nd.link);
+                out[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
                 const uint32_t size = leaf ? 1u : nd.link - my;
                 w += leaf ? 1u + 3u * nd.link : 4u + 6u * (31u - (uint32_t)__clz((int)size));
             }
@@ -500,7 +500,7 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
             break;
         }
         if (pass && leaf) {
-            out[n_out + (uint32_t)__popcll(m_leaf & below)] = make_uint2(my, my + 1u);
+            out[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
             w += 1u + 3u * nd.link;            // its box test and its primitive records
         }
         n_out += n_leaf;
@@ -614,10 +614,10 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         } else if (root < S.n_nodes) {
             // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
             // cut of sixteen subtrees prunes nothing, and what orders such a frame well is the length of a real walk — the
-            // tile's hit pixels towards light sample 0, its result unused.  The cut is the whole tree.  (Measured on the
+            // tile's hit pixels towards light sample 0, its result unused.  No cut is written: shade_tiles_kernel's
+            // whole-stream form walks the stream from its first record.  (Measured on the
             // 1M-triangle soup: 61 ms with this estimate, 65-67 ms with the cut's proxy at any cut size.)
-            if (lane == 0) W.cut[(size_t)tile_id * kMaxCut] = make_uint2(root, S.n_nodes);
-            n_cut = 1u;
+            n_cut = 0u;   // (shade_tiles_kernel's whole-stream form does not read a cut)
             const float *lp = S.light_points + 3u * (r * S.nb_light);
             const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;
             const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -808,8 +808,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     const uint32_t res_stride = lds_res_stride(batch);
     float *const l_pix = l_res + 64u * res_stride;                                    // per pixel: running sums r,g,b + hit slot
     uint32_t *const l_ctl = reinterpret_cast<uint32_t *>(l_pix + 64u * 4u);           // [1] redo flag, [3] tile
-    uint32_t *const l_cut = l_ctl + 4u;                                                // the tile's cut: (begin, end) pairs
-    float *const l_thr = reinterpret_cast<float *>(l_cut + 2u * kMaxCut);               // the 256 gamma thresholds (eight dependent
+    uint32_t *const l_cut = l_ctl + 4u;                                                // the tile's cut: CutEntry records
+    float *const l_thr = reinterpret_cast<float *>(l_cut + kCutWords * kMaxCut);        // the 256 gamma thresholds (eight dependent
     for (uint32_t k = threadIdx.x; k < 256u; k += 64u * NW) l_thr[k] = S.gamma_thr[k];   // reads per channel per pixel: LDS, not L1)
 
 #if RTX_WIDE_WALK
@@ -898,7 +898,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 hit_words[j] = k < 64u * kHitStride ? tile_hits[k] : 0.0f;
             }
         }
-        const uint32_t cut_word = threadIdx.x < 2u * kMaxCut ? reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x] : 0u;
+        const uint32_t cut_word = threadIdx.x < kCutWords * kMaxCut ? reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x] : 0u;
         const uint32_t pix_word = wave == 0u ? W.pix_slot[(size_t)tile_id * 64u + lane] : kNone;   // (with the rest: not behind the descriptor)
         const TileDesc td = W.tiles[tile_id];
         const uint32_t n_all = __builtin_amdgcn_readfirstlane(td.n_hit);
@@ -918,7 +918,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             } else {                                                                 // the part's records [h0, h0 + n_hit) -> LDS [0, n_hit)
                 for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = tile_hits[h0 * kHitStride + k];
             }
-            if (threadIdx.x < 2u * n_cut) l_cut[threadIdx.x] = cut_word;
+            if (threadIdx.x < kCutWords * n_cut) l_cut[threadIdx.x] = cut_word;
             if (wave == 0) {
                 const size_t pix = (size_t)tile_id * 64u + lane;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                               // main.rs:182
@@ -1208,7 +1208,7 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);   // streamed (ablation) pipeline only; 16 B
     b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts) * sizeof(uint32_t) : 0u;
-    b.cut = probe ? tiles * kMaxCut * sizeof(uint2) : 0u;
+    b.cut = probe ? tiles * kMaxCut * sizeof(CutEntry) : 0u;
     return b;
 }
 

@@ -961,7 +961,7 @@ __device__ __forceinline__ bool hit_wide(const WideNode RTX_CONSTANT *__restrict
         return true;
     }
     for (uint32_t k = 0; k < n_cut; ++k) {
-        const uint32_t entry = __builtin_amdgcn_readfirstlane(cut[2u * k]);
+        const uint32_t entry = __builtin_amdgcn_readfirstlane(cut[kCutWords * k]);
         if (use_fast) alive = walk_wide<COUNT, SPHERES, ANYHIT, true>(wide, tris, shade, entry, r, alive, n_active, wc);
         else alive = walk_wide<COUNT, SPHERES, ANYHIT, false>(wide, tris, shade, entry, r, alive, n_active, wc);
         if (ANYHIT && alive == 0ull) break;
@@ -989,12 +989,32 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
         if (alive == 0ull) return;
         if (COUNT) n_active = __popcll(alive);
     }
+    // Each entry brings a copy of its subtree's root record (rtx_device.h: CutEntry): the root's box is tested out of LDS,
+    // and the stream is fetched only below a root that some walking lane passes — a chunk's rays are a thin part of their
+    // tile's shaft and miss most of the cut's roots, each of which used to cost one dependent scalar load.
     // (One loop over all ranges — refilling [i, end) inside walk_range's loop — was measured too: the loop's two-way
     //  exit costs five scalar instructions per record there, this nesting three, the whole-stream walk none.)
     for (uint32_t k = 0; k < n_cut; ++k) {
-        const uint32_t begin = __builtin_amdgcn_readfirstlane(cut[2u * k]);
-        const uint32_t end = __builtin_amdgcn_readfirstlane(cut[2u * k + 1u]);
-        alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin, end, r, alive, n_active, wc);
+        const uint32_t *e = cut + kCutWords * k;
+        NodeRec root;   // NodeDev order: lo.x lo.y hi.x hi.y lo.z hi.z link info
+        root.bmin[0] = __uint_as_float(e[2]); root.bmin[1] = __uint_as_float(e[3]);
+        root.bmax[0] = __uint_as_float(e[4]); root.bmax[1] = __uint_as_float(e[5]);
+        root.bmin[2] = __uint_as_float(e[6]); root.bmax[2] = __uint_as_float(e[7]);
+        root.link = __builtin_amdgcn_readfirstlane(e[8]);
+        root.info = __builtin_amdgcn_readfirstlane(e[9]);
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+        if ((box_mask(USE_FAST, root, r) & alive) == 0ull) continue;
+        if (root.info >> 31) {
+            if (SPHERES && (root.info & kSphereFlag))
+                leaf_spheres<COUNT, true>(tris, shade, root.info & kLeafIndexMask, root.link, r, n_active, wc);
+            else
+                leaf_triangles<COUNT, true, USE_FAST>(tris, shade, root.info & kLeafIndexMask, root.link, r, alive, n_active, wc);
+            alive = ballot(r.active);
+            if (COUNT) n_active = __popcll(alive);
+        } else {
+            const uint32_t begin = __builtin_amdgcn_readfirstlane(e[0]), end = __builtin_amdgcn_readfirstlane(e[1]);
+            alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc);
+        }
         if (alive == 0ull) break;
     }
 }
