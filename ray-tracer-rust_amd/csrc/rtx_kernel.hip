@@ -898,6 +898,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 hit_words[j] = k < 64u * kHitStride ? tile_hits[k] : 0.0f;
             }
         }
+        static_assert(kCutWords * kMaxCut <= 64u * NW, "one word of the cut per work-item");
         const uint32_t cut_word = threadIdx.x < kCutWords * kMaxCut ? reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x] : 0u;
         const uint32_t pix_word = wave == 0u ? W.pix_slot[(size_t)tile_id * 64u + lane] : kNone;   // (with the rest: not behind the descriptor)
         const TileDesc td = W.tiles[tile_id];
