@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development tool: per-tile cost of the shading pass.  Needs a library built with EXTRA=-DRTX_EXPERIMENT_TIMELINE=1
 (every job adds its duration to its tile's descriptor); prints how the frame's workgroup-time splits over the tiles by
-the size of their cut.      python tools/tile_timeline.py [c3|c4|c5|c2]"""
+the size of their cut.      python tools/tile_timeline.py [c3|c4|c5|c2] [resident workgroups]
+(resident workgroups: 256 CUs x 3 of the cut form's 6 waves per SIMD, x 4 of the whole-tree form's 8; default by workload)"""
 import importlib, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +11,7 @@ import torch
 rtx = importlib.import_module("ray-tracer-rust_amd")
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 W, H = {"c3": (1920, 1080), "c2": (1920, 1080), "c4": (4096, 4096), "c5": (4096, 4096)}[wl]
+WGS = int(sys.argv[2]) if len(sys.argv) > 2 else (1024 if wl == "c5" else 768)
 T = rtx.gen_samples()
 if wl == "c5":
     tris, rgb = rtx.synthetic_primitives(1000000)
@@ -30,8 +32,8 @@ n_cut = (flags >> 8) & 0xFF
 us = ticks / 100.0
 work = n_hit > 0
 print(json.dumps({"workload": wl, "tiles": int(len(td)), "tiles_with_hits": int(work.sum()), "shade_ms": float(shade[-1]),
-                  "sched_ms": float(sched[-1]), "sum_job_us": float(us.sum()), "wg_time_available_us": float(shade[-1] * 1e3 * 1024),
-                  "busy_fraction": float(us.sum() / (shade[-1] * 1e3 * 1024))}))
+                  "sched_ms": float(sched[-1]), "sum_job_us": float(us.sum()), "wg_time_available_us": float(shade[-1] * 1e3 * WGS),
+                  "busy_fraction": float(us.sum() / (shade[-1] * 1e3 * WGS))}))
 edges = [0, 1, 2, 4, 8, 16, 32, 64, 65]
 for a, b in zip(edges[:-1], edges[1:]):
     m = work & (n_cut >= a) & (n_cut < b)
