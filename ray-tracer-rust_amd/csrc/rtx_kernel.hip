@@ -975,9 +975,18 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     __builtin_amdgcn_s_setprio(0);
 #endif
                     for (uint32_t c0 = wave * 64u; c0 < total; c0 += 64u * NW) {
+#if RTX_EXPERIMENT_PAIR         // counting experiment only (wrong pixels): what the union of a walk's records grows by when each
+                                // ray is joined by its partner one pixel (pixel-major) or one sample (sample-major) on: lanes
+                                // 0..31 keep their rays; 1: lanes 32..63 idle, 2: lanes 32..63 take the partners
+                        const uint32_t ray_no = c0 + (lane & 31u) + (lane >= 32u ? div : 0u);
+                        const bool valid = ray_no < total && (RTX_EXPERIMENT_PAIR == 2 || lane < 32u);
+                        const uint32_t quo = (uint32_t)(((float)ray_no + 0.5f) * inv_div);
+                        const uint32_t rem = ray_no - __umul24(quo, div);
+#else
                         const bool valid = c0 + lane < total;
                         const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
                         const uint32_t rem = (c0 + lane) - __umul24(quo, div);
+#endif
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         const bool no_ground = have_plane &&
                             (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development tool: per-tile cost of the shading pass.  Needs a library built with EXTRA=-DRTX_EXPERIMENT_TIMELINE=1
 (every job adds its duration to its tile's descriptor); prints how the frame's workgroup-time splits over the tiles by
-the size of their cut.      python tools/tile_timeline.py [c3|c4|c5|c2] [resident workgroups]
+the size of their cut.      python tools/tile_timeline.py [c3|c4|c5|c2] [resident workgroups] [shares]
 (resident workgroups: 256 CUs x 3 of the cut form's 6 waves per SIMD, x 4 of the whole-tree form's 8; default by workload)"""
 import importlib, json, os, sys
 import numpy as np
@@ -12,6 +12,7 @@ rtx = importlib.import_module("ray-tracer-rust_amd")
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 W, H = {"c3": (1920, 1080), "c2": (1920, 1080), "c4": (4096, 4096), "c5": (4096, 4096)}[wl]
 WGS = int(sys.argv[2]) if len(sys.argv) > 2 else (1024 if wl == "c5" else 768)
+SHARES = int(sys.argv[3]) if len(sys.argv) > 3 else 1     # time share 0 of this many (what one GPU of N renders)
 T = rtx.gen_samples()
 if wl == "c5":
     tris, rgb = rtx.synthetic_primitives(1000000)
@@ -19,11 +20,11 @@ if wl == "c5":
 else:
     scene = rtx.default_scene([os.path.join(ROOT, "models", "bunny.obj" if wl == "c2" else "big_bunny.obj")], W, H, T)
 scene.upload(0)
-nb = scene.tiles_bytes(0, 1, 8)
+nb = scene.tiles_bytes(0, SHARES, 8)
 out = torch.zeros(nb, dtype=torch.uint8, device="cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    scene.render_tiles_device(0, 0, 1, 8, out.data_ptr(), nb, st, None)
+    scene.render_tiles_device(0, 0, SHARES, 8, out.data_ptr(), nb, st, None)
 torch.cuda.synchronize()
 sched, shade = scene.launch_timings(0, 3)
 td = scene.tile_descs(0)
