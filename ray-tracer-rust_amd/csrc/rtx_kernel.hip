@@ -678,6 +678,35 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 // whose tiles cost more than kSplitShare of a workgroup's fair share of the launch's estimated cost is cut into the
 // power of two of parts that brings it below, at most kMaxTileParts.
 constexpr uint32_t kOrderHist = kCostBuckets, kOrderCursor = 2u * kCostBuckets, kOrderList = 3u * kCostBuckets;
+// Who takes which job.  The persistent workgroups b, b + 8, b + 16, ... share an XCD and with it an L2 (workgroups are
+// dealt round-robin over the eight XCDs: MI355X_MICROARCH.md, workgroup dispatch); the order is dealt to these eight
+// groups in runs of kClaimRun consecutive jobs — neighbouring tiles of one cost class, or the parts of one tile — so that
+// what one L2 holds (node and primitive records of one region of the scene, a tile's hit records and cut) is what its
+// own compute units ask for next.  Group g's k-th claim is job ((k / run) * 8 + g) * run + k % run of the order: every
+// group still goes through the order costliest first, and a group whose share is used up draws from the next group's
+// ([kOrderClaim + g]: claims of group g, zeroed with the histogram).  Speed only: any workgroup may run any job.
+#ifndef RTX_XCD_QUEUES
+#define RTX_XCD_QUEUES 1
+#endif
+#ifndef RTX_CLAIM_RUN_LOG
+#define RTX_CLAIM_RUN_LOG 10      // runs of 16 / 64 / 256 / 1024 / 4096 jobs: the 1M-triangle soup -1.7 / -2.3 / -3.5 / -4.3 / -3.7 %
+#endif
+constexpr uint32_t kOrderClaim = 8u, kClaimRunLog = RTX_CLAIM_RUN_LOG;
+__device__ __forceinline__ uint32_t claimed_index(uint32_t group, uint32_t k)
+{
+    return ((((k >> kClaimRunLog) << 3) + group) << kClaimRunLog) + (k & ((1u << kClaimRunLog) - 1u));
+}
+// the work-item that claims the jobs: the next job of its XCD's group, or of the groups after it; kNone when all are used up
+__device__ __forceinline__ uint32_t claim_job(uint32_t *__restrict__ buckets, uint32_t n_jobs, uint32_t group0, uint32_t &groups_done)
+{
+    while (groups_done < 8u) {
+        const uint32_t g = (group0 + groups_done) & 7u;
+        const uint32_t idx = claimed_index(g, atomicAdd(&buckets[kOrderClaim + g], 1u));
+        if (idx < n_jobs) return buckets[kOrderList + idx];
+        ++groups_done;
+    }
+    return kNone;
+}
 #ifndef RTX_TILE_PARTS_MAX
 #define RTX_TILE_PARTS_MAX 16
 #endif
@@ -849,6 +878,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     const uint32_t n_jobs = W.buckets[0];
     uint32_t job_ahead = kNone, q_ahead = 0u;
     bool have_ahead = false;
+    // (the whole-stream form only — scenes whose records do not fit an XCD's L2; measured on one box, interleaved, runs of 16:
+    //  the 1M-triangle soup -1.7 %, and with the cut form big_bunny 4096x4096 -0.4 %, 1080p +2 %, the ground-only frame +10 %)
+    constexpr bool xcd_queues = RTX_XCD_QUEUES != 0 && WHOLE;
+    const uint32_t group0 = blockIdx.x & 7u;
+    uint32_t groups_done = 0u, g_ahead = 0u;      // (state of the work-item that claims the jobs)
     // the light points are the same for every job of a launch (main.rs:194-196: sample i of primary ray r): when one batch
     // holds them all they are staged once, not once per job (a global round trip of 2.4 us in front of every job's rays)
     const bool lights_once = S.nb_light <= batch;
@@ -857,8 +891,12 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     for (;;) {
         if (threadIdx.x == 0) {
             if (!have_ahead) {   // the first job, and after jobs without a last phase
-                const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);            // q-th job, costliest class first
-                job_ahead = q < n_jobs ? W.buckets[3u * kCostBuckets + q] : kNone;
+                if (xcd_queues) {
+                    job_ahead = claim_job(W.buckets, n_jobs, group0, groups_done);
+                } else {
+                    const uint32_t q = atomicAdd(&queue[kQueueNextTile], 1u);        // q-th job, costliest class first
+                    job_ahead = q < n_jobs ? W.buckets[kOrderList + q] : kNone;
+                }
             }
             l_ctl[3] = job_ahead;
             have_ahead = false;
@@ -956,7 +994,14 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // neither round trip is waited for.  (A costly job claims when its sums start: claimed a hundred
                     // microseconds ahead, the costliest jobs are tied to workgroups two at a time, +13 % on a 1080p frame.)
                     const bool claim_early = n_cut == 0u;
-                    if (threadIdx.x == 0 && b0 + batch >= S.nb_light && claim_early) q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
+                    if (threadIdx.x == 0 && b0 + batch >= S.nb_light && claim_early) {
+                        if (!xcd_queues) {
+                            q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
+                        } else if (groups_done < 8u) {
+                            g_ahead = (group0 + groups_done) & 7u;
+                            q_ahead = atomicAdd(&W.buckets[kOrderClaim + g_ahead], 1u);
+                        }
+                    }
 #if RTX_EXPERIMENT_PHASES
                     ph_t[2] = wall_clock64();
 #endif
@@ -1031,8 +1076,24 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     if (wave == 0) {
 #endif
                         if (threadIdx.x == 0 && b0 + batch >= S.nb_light) {          // last batch: the claimed position -> job id
-                            if (!claim_early) q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
-                            job_ahead = q_ahead < n_jobs ? W.buckets[3u * kCostBuckets + q_ahead] : kNone;
+                            if (!xcd_queues) {
+                                if (!claim_early) q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
+                                job_ahead = q_ahead < n_jobs ? W.buckets[kOrderList + q_ahead] : kNone;
+                            } else if (groups_done >= 8u) {
+                                job_ahead = kNone;
+                            } else {
+                                if (!claim_early) {
+                                    g_ahead = (group0 + groups_done) & 7u;
+                                    q_ahead = atomicAdd(&W.buckets[kOrderClaim + g_ahead], 1u);
+                                }
+                                const uint32_t idx = claimed_index(g_ahead, q_ahead);
+                                if (idx < n_jobs) {
+                                    job_ahead = W.buckets[kOrderList + idx];
+                                } else {       // the group's share is used up: on to the next group's (the end of a launch only)
+                                    ++groups_done;
+                                    job_ahead = claim_job(W.buckets, n_jobs, group0, groups_done);
+                                }
+                            }
                             have_ahead = true;
                         }
                         const uint32_t slot = reinterpret_cast<const uint32_t *>(l_pix)[4u * lane + 3u];
