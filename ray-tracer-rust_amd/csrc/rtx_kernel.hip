@@ -71,6 +71,31 @@ __device__ __forceinline__ bool tile_pixel(const DeviceScene &S, const TileSpec 
     return px < S.width && ly < ts.local_rows && py < S.height;
 }
 
+// Tile numbering of the two-pass pipeline: 8 x 8 tiles (64 x 64 pixels) form a block whose tiles are numbered
+// consecutively, blocks row by row — consecutive tile numbers (what one XCD is dealt: probe_kernel's workgroups, the
+// runs of shade_tiles_kernel's order) are then a compact patch of the frame, not a strip eight pixels high, and their
+// rays meet the same part of the scene.  The blocks of the right and lower edge are padded: a tile outside the frame
+// has no pixel (tile_pixel) and ends as a tile without a hit.  0: row-major (the single-kernel ablation variants).
+#ifndef RTX_TILE_BLOCKS
+#define RTX_TILE_BLOCKS 1
+#endif
+__host__ __device__ inline uint32_t numbered_tiles(uint32_t tiles_x, uint32_t tiles_y)
+{
+    return RTX_TILE_BLOCKS ? ((tiles_x + 7u) / 8u) * ((tiles_y + 7u) / 8u) * 64u : tiles_x * tiles_y;
+}
+__device__ __forceinline__ void tile_xy(uint32_t tile_id, uint32_t tiles_x, bool blocks, uint32_t &tx, uint32_t &ty)
+{
+    if (blocks) {
+        const uint32_t blocks_x = (tiles_x + 7u) >> 3, b = tile_id >> 6, j = tile_id & 63u;
+        const uint32_t by = b / blocks_x, bx = b - by * blocks_x;
+        tx = bx * 8u + (j & 7u);
+        ty = by * 8u + (j >> 3);
+    } else {
+        ty = tile_id / tiles_x;
+        tx = tile_id - ty * tiles_x;
+    }
+}
+
 // create_rays (main.rs:151-178) + Ray::new (ray.rs:12-17) for ray r of pixel (px, py)
 __device__ __forceinline__ void primary_ray(const DeviceScene &S, bool in_frame, uint32_t px, uint32_t py, uint32_t r,
                                             float &dx, float &dy, float &dz)
@@ -207,7 +232,8 @@ template <bool COUNT, bool SPHERES = false>
 __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x,
                                                               uint8_t *__restrict__ out,
                                                               const uint32_t *__restrict__ redo,
-                                                              unsigned long long *__restrict__ counters)
+                                                              unsigned long long *__restrict__ counters,
+                                                              bool tile_blocks = false)
 {
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
     const bool have_ref = S.n_ref_nodes != 0u;
@@ -220,7 +246,9 @@ __global__ void __launch_bounds__(64) reference_tiles_kernel(DeviceScene S, Tile
     for (uint32_t q = blockIdx.x; q < n_redo; q += gridDim.x) {
         const uint32_t tid = __builtin_amdgcn_readfirstlane(redo[kQueueHeader + q]);
         uint32_t px, py, ly;
-        const bool in_frame = tile_pixel(S, ts, tid % tiles_x, tid / tiles_x, lane, px, py, ly);
+        uint32_t tile_x, tile_y;
+        tile_xy(tid, tiles_x, tile_blocks, tile_x, tile_y);
+        const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
         float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
         const float denom = (float)(S.nb_ray * S.nb_light);
         for (uint32_t r = 0; r < S.nb_ray; ++r) {
@@ -302,6 +330,9 @@ constexpr uint32_t kChunkFixedCost = 8u;
 constexpr uint32_t kCutMaxNodes = 1u << 16;
 
 // independent wavefronts (tiles) per workgroup of probe_kernel: 1, 4 and 8 measured the same (m_ab_probewaves.log)
+#ifndef RTX_PROBE_XCD
+#define RTX_PROBE_XCD 1
+#endif
 #ifndef RTX_PROBE_WAVES
 #define RTX_PROBE_WAVES 1
 #endif
@@ -533,10 +564,20 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *const l_front = l_front_all[wave_in_group];
+#if RTX_PROBE_XCD
+    // workgroups b, b + 8, ... share an XCD (MI355X_MICROARCH.md, workgroup dispatch): the XCDs are dealt runs of 64
+    // consecutive tile numbers — one 64 x 64 pixel block each — so that an L2 serves neighbouring tiles' walks.  (One
+    // contiguous eighth of the frame per XCD was 25-35 % slower: the upper half of a frame is sky.)
+    static_assert(RTX_PROBE_WAVES == 1, "the XCD mapping assumes one tile per workgroup");
+    const uint32_t k = blockIdx.x >> 3;
+    const uint32_t tile_id = ((((k >> 6) << 3) + (blockIdx.x & 7u)) << 6) + (k & 63u);
+#else
     const uint32_t tile_id = blockIdx.x * RTX_PROBE_WAVES + wave_in_group;
+#endif
     if (tile_id >= n_tiles) return;
-    uint32_t px, py, ly;
-    const bool in_frame = tile_pixel(S, ts, tile_id % tiles_x, tile_id / tiles_x, lane, px, py, ly);
+    uint32_t px, py, ly, tile_x, tile_y;
+    tile_xy(tile_id, tiles_x, RTX_TILE_BLOCKS != 0, tile_x, tile_y);
+    const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
     WaveCounters wc;
     float dx, dy, dz;
     primary_ray(S, in_frame, px, py, r, dx, dy, dz);
@@ -922,7 +963,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         // part `part` of 2^parts_log of the tile: its hit records [h0, h0 + n_hit), the pixels they belong to, and (part 0)
         // the tile's pixels without a hit
         const uint32_t tile_id = job & kJobTileMask, part = (job >> kJobTileBits) & 15u, parts_log = job >> kJobPartsShift;
-        const uint32_t tile_x = tile_id % tiles_x, tile_y = tile_id / tiles_x;
+        uint32_t tile_x, tile_y;
+        tile_xy(tile_id, tiles_x, RTX_TILE_BLOCKS != 0, tile_x, tile_y);
         // A whole tile's job requests everything it needs from HBM at once — the tile's descriptor, all 64 of its hit-record
         // slots, its pixel slots, its cut list — and sorts it out when it is there: waiting for the descriptor first, to ask
         // only for the records that exist, made two dependent round trips in front of every such job.  A PART of a tile
@@ -1207,7 +1249,7 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
     const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
-    const uint32_t n_tiles = tiles_x * tiles_y;
+    const uint32_t n_tiles = numbered_tiles(tiles_x, tiles_y);
     // persistent grid = what the device keeps resident of the form that is launched (the two forms differ in registers)
     static thread_local int cached_dev = -1, cached_blocks = 0;
     static thread_local size_t cached_lds = 0;
@@ -1233,7 +1275,8 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
         if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(W.buckets, 0, 3u * kCostBuckets * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>), dim3((n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
+        hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>),
+                           dim3(RTX_PROBE_XCD ? 512u * ((n_tiles + 511u) / 512u) : (n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
                            dim3(64 * RTX_PROBE_WAVES), 0, stream, S, ts, tiles_x, n_tiles,
                            r, W, d_out, d_redo, d_counters);
         hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
@@ -1248,7 +1291,7 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL((reference_tiles_kernel<COUNT, SPHERES>), dim3(n_tiles < 1024u ? n_tiles : 1024u), dim3(64), 0, stream,
-                       S, ts, tiles_x, d_out, d_redo, d_counters);
+                       S, ts, tiles_x, d_out, d_redo, d_counters, RTX_TILE_BLOCKS != 0);
     return hipGetLastError();
 }
 
@@ -1262,12 +1305,14 @@ uint32_t trace_tiles_x(const DeviceScene &S, uint32_t variant) { return (S.width
 
 size_t trace_redo_bytes(const DeviceScene &S, const TileSpec &ts)
 {
-    return sizeof(uint32_t) * (kQueueHeader + static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u));
+    return sizeof(uint32_t) * (kQueueHeader + static_cast<size_t>(numbered_tiles((S.width + 7u) / 8u, (ts.local_rows + 7u) / 8u)));
 }
 
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant)
 {
-    const size_t tiles = static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u);
+    const bool two_pass = (variant & kVariantProbe) != 0u;
+    const size_t tiles = two_pass ? numbered_tiles((S.width + 7u) / 8u, (ts.local_rows + 7u) / 8u)
+                                  : static_cast<size_t>((S.width + 7u) / 8u) * ((ts.local_rows + 7u) / 8u);
     const size_t pixels = tiles * 64u;
     const bool streamed = (variant & kVariantStream) != 0u, probe = (variant & kVariantProbe) != 0u;
     StreamWorkspaceBytes b;

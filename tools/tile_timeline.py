@@ -43,4 +43,7 @@ for a, b in zip(edges[:-1], edges[1:]):
             a, b - 1, int(m.sum()), us[m].sum(), 100 * us[m].sum() / us.sum(), us[m].mean(), us[m].max(), n_hit[m].mean()))
 top = np.argsort(-us)[:8]
 tx = (W + 7) // 8
-print("costliest tiles:", [(int(t % tx), int(t // tx), int(n_cut[t]), int(n_hit[t]), round(float(us[t]), 1)) for t in top])
+def tile_xy(t):   # the library numbers tiles by 8 x 8 blocks (rtx_kernel.hip: tile_xy)
+    blocks_x, b, j = (tx + 7) // 8, t >> 6, t & 63
+    return (b % blocks_x) * 8 + (j & 7), (b // blocks_x) * 8 + (j >> 3)
+print("costliest tiles:", [tile_xy(int(t)) + (int(n_cut[t]), int(n_hit[t]), round(float(us[t]), 1)) for t in top])
