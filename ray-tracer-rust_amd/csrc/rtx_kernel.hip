@@ -173,11 +173,38 @@ __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, f
     if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? lnd : kOccluded;
 }
 
+// x / denom for the divisor a whole launch shares (denom = NB_RAY * NB_LIGHT_SAMPLE, main.rs:211): the compiler's IEEE
+// division without its range scaling and fix-up — y = 1/denom once per kernel (reciprocal_ieee's steps), then q0 = x*y,
+// r0 = x - denom*q0, q1 = q0 + r0*y, r1 = x - denom*q1, q = q1 + r1*y with fused residuals, five instructions instead of
+// eleven.  The left-out steps do nothing for x = 0 and for 2^-60 <= x with 1 <= denom <= 2^30 (rtx_traverse.hpp:
+// divide3_ieee): the same instructions on the same values, the same bits — tools/div_denom_check.hip compares every
+// binary32 x in [2^-60, 4) for eighteen divisors.  A wavefront with a lane outside (tiny, negative, NaN) divides.
+struct DenomDiv { float d, y; bool usable; };
+__device__ __forceinline__ DenomDiv denom_div(float denom)
+{
+    DenomDiv dd;
+    dd.d = denom;
+    const float y0 = __builtin_amdgcn_rcpf(denom);
+    dd.y = __builtin_fmaf(y0, __builtin_fmaf(-denom, y0, 1.0f), y0);
+    dd.usable = denom >= 1.0f && denom <= 0x1p30f;
+    return dd;
+}
+__device__ __forceinline__ float div_denom(float x, const DenomDiv &dd)
+{
+    if (!dd.usable || ballot(!(x == 0.0f || x >= 0x1p-60f)) != 0ull) return x / dd.d;
+    const float q0 = x * dd.y;
+    const float r0 = __builtin_fmaf(-dd.d, q0, x);
+    const float q1 = __builtin_fmaf(r0, dd.y, q0);
+    const float r1 = __builtin_fmaf(-dd.d, q1, x);
+    return __builtin_fmaf(r1, dd.y, q1);
+}
+
 // The same for a tile whose hit pixels are all grey (red == green == blue >= 0, equal running sums): the lane stores
 // the sample's contribution (color.red * lnd) / denom itself (main.rs:211-215), so that the ordered accumulation,
 // which one wavefront does alone, is left with the additions.  Contributions are >= 0 (or NaN), the marker is not.
+template <bool FAST_DIV>
 __device__ __forceinline__ void shadow_result_grey(const float *__restrict__ l_hit, float *__restrict__ l_res,
-                                                   uint32_t res_stride, const ShadowRay &s, float denom)
+                                                   uint32_t res_stride, const ShadowRay &s, const DenomDiv &dd)
 {
     const float *h = l_hit + __umul24(kHitStride, s.hp);
     const LaneRay &r = s.ray;
@@ -185,7 +212,35 @@ __device__ __forceinline__ void shadow_result_grey(const float *__restrict__ l_h
     const bool lit = r.best_idx == kNone;
     // an occluded sample contributes (black * 1.0) / denom = +0.0 (main.rs:226): adding it changes no sum of this kind
     // (they start at +0.0 and only grow), so the ordered accumulation needs no test
-    if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? (h[6] * lnd) / denom : 0.0f;
+    const float c = FAST_DIV ? div_denom(h[6] * lnd, dd) : (h[6] * lnd) / dd.d;
+    if (s.valid) l_res[__umul24(s.hp, res_stride) + s.si] = lit ? c : 0.0f;
+}
+
+// A FULL tile numbered sample-major (64 hit pixels of one surface — nearly every tile of the ground): chunk c is light
+// sample c for the 64 pixels, lane l carries pixel l in every chunk.  The lane's hit record stays in registers for the
+// whole job (h[0..2] p_hit, h[3..5] normal, h[6] red) and the ray number needs no division.
+__device__ __forceinline__ ShadowRay shadow_ray_full(const float (&h)[7], const float *__restrict__ l_light, uint32_t lane, uint32_t sample)
+{
+    ShadowRay s;
+    s.hp = lane;
+    s.si = sample;
+    const float *lp = l_light + 3u * sample;
+    const float vx = lp[0] - h[0], vy = lp[1] - h[1], vz = lp[2] - h[2];             // p - orig
+    float dist_light, sx, sy, sz;
+    length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);                         // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
+    s.ray = make_ray_bare(true, h[0], h[1], h[2], sx, sy, sz);
+    s.ray.limit = dist_light;
+    s.valid = true;
+    return s;
+}
+__device__ __forceinline__ void shadow_result_grey_full(const float (&h)[7], float *__restrict__ l_res, uint32_t res_stride,
+                                                        const ShadowRay &s, const DenomDiv &dd)
+{
+    const LaneRay &r = s.ray;
+    const float lnd = fabsf(h[3] * r.dx + h[4] * r.dy + h[5] * r.dz);               // main.rs:207
+    const bool lit = r.best_idx == kNone;
+    const float c = div_denom(h[6] * lnd, dd);                                       // main.rs:211
+    l_res[__umul24(s.hp, res_stride) + s.si] = lit ? c : 0.0f;                        // (see shadow_result_grey)
 }
 
 __device__ __forceinline__ void store_pixel(const DeviceScene &S, const float *__restrict__ thr, uint8_t *__restrict__ out,
@@ -862,6 +917,9 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 #ifndef RTX_SHADE_PRIORITY
 #define RTX_SHADE_PRIORITY 1
 #endif
+#ifndef RTX_FULL_TILE_PATH
+#define RTX_FULL_TILE_PATH 1
+#endif
 #ifndef RTX_SHADE_CUT_WAVES_PER_SIMD
 #define RTX_SHADE_CUT_WAVES_PER_SIMD 6
 #endif
@@ -905,6 +963,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     constexpr bool whole_tree = WHOLE;
 #endif
     const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
+    const DenomDiv denom_d = denom_div(denom);
     static_assert(sizeof(HitRec) == kHitStride * sizeof(float), "the LDS hit record is the HBM hit record");
 
 #if RTX_EXPERIMENT_TIMELINE     // timing experiment only: a job's duration (100 MHz ticks, claim to next claim) is added to its
@@ -1023,6 +1082,14 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 const bool grey_tile = ballot(hit && !(cr == cg && cg == cb && cr >= 0.0f && a0 == a1 && a1 == a2)) == 0ull;
                 if (lane == 0) l_ctl[2] = grey_tile ? 1u : 0u;   // read behind the barrier that publishes the light points
             }
+            // a full tile numbered sample-major keeps each lane's hit record in registers (shadow_ray_full); cut form only:
+            // the whole-stream form has no registers to spare
+            const bool full_tile = RTX_FULL_TILE_PATH != 0 && !WHOLE && sample_major && n_hit == 64u;
+            float my_hit[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (full_tile) {
+#pragma unroll
+                for (uint32_t k = 0; k < 7u; ++k) my_hit[k] = l_hit[kHitStride * lane + k];
+            }
             if (n_hit != 0u) {                                                        // else main.rs:235
                 for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                 // main.rs:193, in batches that fit LDS
                     const uint32_t bc = (S.nb_light - b0 < batch) ? S.nb_light - b0 : batch;
@@ -1069,12 +1136,18 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         const bool valid = ray_no < total && (RTX_EXPERIMENT_PAIR == 2 || lane < 32u);
                         const uint32_t quo = (uint32_t)(((float)ray_no + 0.5f) * inv_div);
                         const uint32_t rem = ray_no - __umul24(quo, div);
-#else
-                        const bool valid = c0 + lane < total;
-                        const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
-                        const uint32_t rem = (c0 + lane) - __umul24(quo, div);
-#endif
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
+#else
+                        ShadowRay sr;
+                        if (full_tile) {   // chunk = light sample c0 / 64 of the tile's 64 pixels
+                            sr = shadow_ray_full(my_hit, l_light, lane, c0 >> 6);
+                        } else {
+                            const bool valid = c0 + lane < total;
+                            const uint32_t quo = (uint32_t)(((float)(c0 + lane) + 0.5f) * inv_div);
+                            const uint32_t rem = (c0 + lane) - __umul24(quo, div);
+                            sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
+                        }
+#endif
                         const bool no_ground = have_plane &&
                             (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
                         // A chunk with nothing to walk — no subtree in the tile's cut, and the ground (the only global triangle)
@@ -1101,7 +1174,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
 #endif
                         if (!ok && lane == 0) l_ctl[1] = 1u;
-                        if (grey_tile) shadow_result_grey(l_hit, l_res, res_stride, sr, denom);
+                        if (grey_tile && full_tile) shadow_result_grey_full(my_hit, l_res, res_stride, sr, denom_d);
+                        else if (grey_tile) shadow_result_grey<!WHOLE>(l_hit, l_res, res_stride, sr, denom_d);   // (whole-stream form: no registers to spare, +0.7 %)
                         else shadow_result(l_hit, l_res, res_stride, sr);
                     }
 #if RTX_SHADE_PRIORITY
