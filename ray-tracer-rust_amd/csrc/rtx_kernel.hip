@@ -141,6 +141,7 @@ struct ShadowRay {
     LaneRay ray;
     uint32_t hp, si;
     bool valid;          // the lane carries a ray (ray.active is consumed by the any-hit walk)
+    bool not_hard;       // wave-uniform: no lane's direction is "hard" (length_and_direction took its short way)
 };
 
 // (quo, rem) = ray number / and % the tile's divisor, see the callers; indices are small: 24-bit multiplies are full rate
@@ -155,7 +156,7 @@ __device__ __forceinline__ ShadowRay shadow_ray_at(const float *__restrict__ l_h
     const float hx = h[0], hy = h[1], hz = h[2];
     const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;                   // p - orig
     float dist_light, sx, sy, sz;
-    length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);                         // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
+    s.not_hard = length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);            // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
     s.ray = make_ray_bare(valid, hx, hy, hz, sx, sy, sz);     // the caller adds the culling constants when the ray walks
     s.ray.limit = dist_light;
     s.valid = valid;
@@ -227,7 +228,7 @@ __device__ __forceinline__ ShadowRay shadow_ray_full(const float (&h)[7], const 
     const float *lp = l_light + 3u * sample;
     const float vx = lp[0] - h[0], vy = lp[1] - h[1], vz = lp[2] - h[2];             // p - orig
     float dist_light, sx, sy, sz;
-    length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);                         // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
+    s.not_hard = length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);            // main.rs:202; Ray::new, main.rs:201 -> ray.rs:15
     s.ray = make_ray_bare(true, h[0], h[1], h[2], sx, sy, sz);
     s.ray.limit = dist_light;
     s.valid = true;
@@ -1086,9 +1087,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             // the whole-stream form has no registers to spare
             const bool full_tile = RTX_FULL_TILE_PATH != 0 && !WHOLE && sample_major && n_hit == 64u;
             float my_hit[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            PlaneOrigin my_plane = {0.0f, 0.0f};          // the origin's part of the ground's certificate (plane_rules_out)
             if (full_tile) {
 #pragma unroll
                 for (uint32_t k = 0; k < 7u; ++k) my_hit[k] = l_hit[kHitStride * lane + k];
+                if (have_plane) my_plane = plane_origin(plane0, my_hit[0], my_hit[1], my_hit[2]);
             }
             if (n_hit != 0u) {                                                        // else main.rs:235
                 for (uint32_t b0 = 0; b0 < S.nb_light; b0 += batch) {                 // main.rs:193, in batches that fit LDS
@@ -1149,7 +1152,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
 #endif
                         const bool no_ground = have_plane &&
-                            (ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
+                            (full_tile ? ballot(!plane_rules_out(plane0, my_plane, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull
+                                       : ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
                         // A chunk with nothing to walk — no subtree in the tile's cut, and the ground (the only global triangle)
                         // ruled out from its plane — is lit; what is left of the walk's own prologue is its refusal of hard
                         // directions (closest_hit: such a tile is re-rendered against the reference's tree).  Three of four
@@ -1164,7 +1168,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 #else
                         const bool nothing_to_walk = n_cut == 0u && !whole_tree && (S.n_global == 0u || (S.n_global == 1u && no_ground));
                         if (nothing_to_walk) {
-                            ok = ballot(sr.ray.active && direction_is_hard(sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull;
+                            ok = sr.not_hard || ballot(sr.ray.active && direction_is_hard(sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull;
                         } else {
                             ray_cull_constants(sr.ray);                              // main.rs:204
                             if (whole_tree)

@@ -479,7 +479,10 @@ __device__ __forceinline__ void divide3_ieee(float ax, float ay, float az, float
 //            [2^-90, 2^100] (tools/sqrt_exhaustive.hip: 1.6e9 inputs, 0 differences)
 //   quotient divide3_ieee's shared-reciprocal steps; its ranges follow from 2^-45 <= |component| and x <= 2^100
 // A wavefront with a lane outside (a zero component, for one) takes sqrtf and the divisions.
-__device__ __forceinline__ void length_and_direction(float vx, float vy, float vz, float &len, float &dx, float &dy,
+// Returns true when the wavefront took the short way: every lane's direction then has finite, NON-ZERO components of
+// magnitude at most 1 + a few ulp (|v_c| >= 2^-45 over a length of at most 2^50) — in particular it is not "hard"
+// (direction_is_hard: a component -0.0, NaN or beyond 2).
+__device__ __forceinline__ bool length_and_direction(float vx, float vy, float vz, float &len, float &dx, float &dy,
                                                      float &dz)
 {
     const float x = vx * vx + vy * vy + vz * vz;
@@ -487,7 +490,7 @@ __device__ __forceinline__ void length_and_direction(float vx, float vy, float v
     if ((ballot(smallest >= 0x1p-45f) & ballot(x <= 0x1p100f)) != ballot(true)) {
         len = sqrtf(x);
         dx = vx / len; dy = vy / len; dz = vz / len;
-        return;
+        return false;
     }
     const float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
@@ -501,6 +504,7 @@ __device__ __forceinline__ void length_and_direction(float vx, float vy, float v
     q0 = vx * y; r0 = __builtin_fmaf(-b, q0, vx); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, vx); dx = __builtin_fmaf(r1, y, q1);
     q0 = vy * y; r0 = __builtin_fmaf(-b, q0, vy); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, vy); dy = __builtin_fmaf(r1, y, q1);
     q0 = vz * y; r0 = __builtin_fmaf(-b, q0, vz); q1 = __builtin_fmaf(r0, y, q0); r1 = __builtin_fmaf(-b, q1, vz); dz = __builtin_fmaf(r1, y, q1);
+    return true;
 }
 
 // A whole 64-byte primitive record with one scalar load, its byte offset in a scalar register (see load_node_at).
@@ -684,17 +688,32 @@ __device__ __forceinline__ NodeRec load_node_at(const NodeRec RTX_CONSTANT *base
 // None as well).  NaN, inf and underflow fail every comparison and leave the full test in place; the allowances
 // carry 2^-100 for flushed products.  The kernel evaluates this next to the ray's set-up, for the FIRST global
 // triangle only, and tells the walk to leave that triangle out when every one of its lanes is certified.
-__device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float oy, float oz, float dx, float dy, float dz)
+// The part of the certificate that depends on the ray's ORIGIN only (a full tile's lane keeps its origin for a whole
+// job: rtx_kernel.hip, shadow_ray_full): lhs = (|s_n| + k A_n)(1 + 2^-19), and s_n itself where |s_n| > k A_n, else 0
+// (a zero makes "moving away" false).
+struct PlaneOrigin { float lhs, sn; };
+__device__ __forceinline__ PlaneOrigin plane_origin(const TriRec &g, float ox, float oy, float oz)
 {
     const float tvx = ox - g.v0[0], tvy = oy - g.v0[1], tvz = oz - g.v0[2];          // triangle.rs:78
     const float sn = __builtin_fmaf(tvz, g.e1[2], __builtin_fmaf(tvy, g.e1[1], tvx * g.e1[0]));
     const float an = __builtin_fmaf(fabsf(tvz), g.e2[2], __builtin_fmaf(fabsf(tvy), g.e2[1], fabsf(tvx) * g.e2[0]));
-    const float sd = __builtin_fmaf(dz, g.e1[2], __builtin_fmaf(dy, g.e1[1], dx * g.e1[0]));
     const float kan = __builtin_fmaf(an, 0x1p-19f, 0x1p-100f);
+    PlaneOrigin po;
+    po.lhs = (fabsf(sn) + kan) * (1.0f + 0x1p-19f);
+    po.sn = fabsf(sn) > kan ? sn : 0.0f;       // (a NaN fails the comparison: 0)
+    return po;
+}
+__device__ __forceinline__ bool plane_rules_out(const TriRec &g, const PlaneOrigin &po, float dx, float dy, float dz)
+{
+    const float sd = __builtin_fmaf(dz, g.e1[2], __builtin_fmaf(dy, g.e1[1], dx * g.e1[0]));
     const float kd = g.bmin[0];
-    const bool magnitude = (fabsf(sn) + kan) * (1.0f + 0x1p-19f) < fabsf(sd) - kd;
-    const bool away = sn * sd > 0.0f && fabsf(sn) > kan && fabsf(sd) > kd;
+    const bool magnitude = po.lhs < fabsf(sd) - kd;
+    const bool away = po.sn * sd > 0.0f && fabsf(sd) > kd;
     return magnitude || away;
+}
+__device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    return plane_rules_out(g, plane_origin(g, ox, oy, oz), dx, dy, dz);
 }
 
 // The walk itself over the records [i, end) of the stream, for one kind of box test (USE_FAST: the multiply-based
