@@ -112,10 +112,8 @@ __device__ __forceinline__ void primary_ray(const DeviceScene &S, bool in_frame,
     const float rx = (a * S.cu[0] + b * S.cv[0]) - S.distance * S.cw[0];             // :160-167
     const float ry = (a * S.cu[1] + b * S.cv[1]) - S.distance * S.cw[1];
     const float rz = (a * S.cu[2] + b * S.cv[2]) - S.distance * S.cw[2];
-    const float rn = sqrtf(rx * rx + ry * ry + rz * rz);                             // ray.rs:15
-    dx = rx / rn;
-    dy = ry / rn;
-    dz = rz / rn;
+    float rn;
+    (void)length_and_direction(rx, ry, rz, rn, dx, dy, dz);                          // ray.rs:15: sqrt, three divisions (bit for bit)
 }
 
 // HitInfo.normal = p.get_normal(p_hit) (bvh.rs:72, mod.rs:80-87): the stored normal of a triangle (triangle.rs:29),
@@ -453,19 +451,27 @@ __device__ __forceinline__ bool shaft_meets(const Shaft &sh, const NodeDev &b)
     return !(s_lo > s_hi);   // a NaN can only accept
 }
 
-// wave-wide minimum / maximum over the lanes (every lane gets the result)
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-}
+// wave-wide minimum / maximum over the lanes, as a scalar: six data-parallel-primitive steps on the vector unit (shifts
+// within the rows of 16 lanes, then lane 15 of a row to the next row, lane 31 to the upper half; lanes a step does not
+// reach keep their value) leave the result in lane 63.  (Through LDS — six ds_bpermute per reduction — the tile's six
+// bounds were 36 LDS round trips in probe_kernel's path.)
+// (inline assembly: through the builtins each step is four instructions — a copy, the shifted copy, a NaN-quieting
+//  maximum, the minimum —; s_nop 1: a DPP operand written by the instruction before needs two wait states)
+#define RTX_DPP_REDUCE(name, insn)                                                                                          \
+    __device__ __forceinline__ float name(float v)                                                                          \
+    {                                                                                                                       \
+        asm volatile("s_nop 1\n\t" insn " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                              \
+                     "s_nop 1\n\t" insn " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                              \
+                     "s_nop 1\n\t" insn " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                              \
+                     "s_nop 1\n\t" insn " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                              \
+                     "s_nop 1\n\t" insn " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                           \
+                     "s_nop 1\n\t" insn " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                           \
+                     "s_nop 1" : "+v"(v));                                                                                  \
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));                                            \
+    }
+RTX_DPP_REDUCE(wave_min, "v_min_f32_dpp")
+RTX_DPP_REDUCE(wave_max, "v_max_f32_dpp")
+#undef RTX_DPP_REDUCE
 // a value every lane holds, moved to a scalar register (the builtin is typed int: the bits go through, not the value)
 __device__ __forceinline__ float uniform(float v)
 {
@@ -688,9 +694,9 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     const uint32_t n_chunks = (n_hit * S.nb_light + 63u) / 64u;
     if (n_hit != 0u && S.nb_light != 0u && !(flags & 2u)) {
         const float inf = __builtin_inff();
-        const float olx = uniform(wave_min(hit ? hx : inf)), ohx = uniform(wave_max(hit ? hx : -inf));
-        const float oly = uniform(wave_min(hit ? hy : inf)), ohy = uniform(wave_max(hit ? hy : -inf));
-        const float olz = uniform(wave_min(hit ? hz : inf)), ohz = uniform(wave_max(hit ? hz : -inf));
+        const float olx = wave_min(hit ? hx : inf), ohx = wave_max(hit ? hx : -inf);
+        const float oly = wave_min(hit ? hy : inf), ohy = wave_max(hit ? hy : -inf);
+        const float olz = wave_min(hit ? hz : inf), ohz = wave_max(hit ? hz : -inf);
         const float *lb = S.light_boxes + 6u * r;
         Shaft sh;
         sh.lower = 0u; sh.upper = 0u;
