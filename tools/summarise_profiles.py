@@ -51,7 +51,9 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(dst, exist_ok=True)
     counters, durations = {}, {}
-    for i, path in enumerate(sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv")))):
+    paths = sorted(glob.glob(os.path.join(src, "pmc*", "%s_counter_collection.csv" % wl))) or \
+        sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv")))
+    for i, path in enumerate(paths):
         c, d = load_counters(path)
         for k, v in c.items():
             counters.setdefault(k, {}).update(v)
@@ -59,7 +61,7 @@ def main():
             durations.setdefault(k, []).append(v)
         group = "_".join(sorted({n for v in c.values() for n in v}))[:60].lower()
         shutil.copy(path, os.path.join(dst, "%s_pmc_%s_%s.csv" % (tag, wl, group)))
-    stats = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
+    stats = glob.glob(os.path.join(src, "stats", "%s_kernel_stats.csv" % wl)) or glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, wl)))
     bench = os.path.join(src, "bench_%s.json" % wl)
