@@ -198,7 +198,10 @@ int rtx_debug_wave_profile(RtxScene *scene, int device, uint32_t row0, uint32_t 
 int rtx_launch_timings(RtxScene *scene, int device, int max_launches, float *schedule_ms, float *shade_ms);
 
 /* Diagnostics: the tile descriptors the most recent launch on `device` left in the library's workspace, one per 8x8
- * tile of that launch, row-major, four uint32 each: {cost class (0xFFFFFFFF: finished by the scheduling pass), primary
+ * tile of that launch, four uint32 each.  Tiles are numbered by 8 x 8 BLOCKS of tiles (64 x 64 pixels), blocks row by row
+ * over ceil(tiles_x / 8) x ceil(tiles_y / 8) blocks, the tiles of a block row by row: tile number t is tile
+ * (x, y) = ((t / 64 % blocks_x) * 8 + t % 8, (t / 64 / blocks_x) * 8 + t % 64 / 8); numbers whose (x, y) lies outside
+ * the launch's tiles are padding (no hits).  Each descriptor: {cost class (0xFFFFFFFF: finished by the scheduling pass), primary
  * hits, flags (bit 0 sample-major numbering, bit 1 re-rendered by the reference walk, bits 8-15 entries of the tile's
  * cut), reserved}.  Call with out == NULL to get the count.  Blocks until the device is idle.  Returns the number of
  * tiles written (<= max_tiles) or a negative RtxError. */

@@ -128,6 +128,36 @@ def test_render_frame_with_several_shares_on_one_device(rtx, samples_seeded):
         assert e.value.code == rtx.ERR_NO_DEVICE
 
 
+def test_tile_descriptors_follow_the_documented_block_numbering(rtx, samples_seeded):
+    """include/rtx.h, rtx_debug_tile_descs: tiles are numbered by 8 x 8 blocks; padding tiles hold no hit; per tile the
+    hit count equals the number of non-sky pixels of the frame the same launch produced (the default scene's sky is the only
+    black: every hit pixel of a ragged 203 x 117 frame is lit by at least one sample or lies on the grey ground)."""
+    W, H = 203, 117
+    with rtx.default_scene([model("big_bunny.obj")], W, H, samples_seeded) as s:
+        img, st = s.render_rows(stats=True)
+        td = s.tile_descs(0)
+    tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+    blocks_x, blocks_y = (tiles_x + 7) // 8, (tiles_y + 7) // 8
+    assert len(td) == blocks_x * blocks_y * 64
+    assert int(td[:, 1].sum()) == st["primary_hits"]
+    seen = set()
+    for t in range(len(td)):
+        b, j = t >> 6, t & 63
+        x, y = (b % blocks_x) * 8 + (j & 7), (b // blocks_x) * 8 + (j >> 3)
+        n_hit = int(td[t, 1])
+        if x >= tiles_x or y >= tiles_y:
+            assert n_hit == 0 and td[t, 0] == 0xFFFFFFFF, "padding tile %d holds work" % t
+            continue
+        seen.add((x, y))
+        patch = img[y * 8:(y + 1) * 8, x * 8:(x + 1) * 8]
+        assert n_hit <= patch.shape[0] * patch.shape[1]
+        if n_hit == 0:
+            assert not patch.any(), "tile (%d, %d): no hit but a lit pixel" % (x, y)
+        else:
+            assert int((patch.max(axis=2) > 0).sum()) <= n_hit
+    assert len(seen) == tiles_x * tiles_y
+
+
 def test_device_resident_entry_point(rtx, samples_seeded):
     """rtx_render_tiles_device writes into caller-owned device memory on the caller's stream
     (torch tensor + torch stream: the bench.py plumbing)."""
