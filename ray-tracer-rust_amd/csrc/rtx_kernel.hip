@@ -928,11 +928,19 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 #ifndef RTX_OPEN_GROUND_LOOP
 #define RTX_OPEN_GROUND_LOOP 1
 #endif
+#ifndef RTX_FULL_TILE_GENERAL      // 1: the general chunk loop, too, works on a full tile's registers
+#define RTX_FULL_TILE_GENERAL 1
+#endif
 #ifndef RTX_FULL_TILE_PATH
 #define RTX_FULL_TILE_PATH 1
 #endif
+// (The cut form at 6 was 3-7 % faster than at 8 while a cheap job was bound by its serial stretches; since the open
+//  ground's chunks are bound by their vector instructions — the loop of their own below — 8 is, although ten vector
+//  registers then live in scratch: big_bunny 4096x4096 -4.6 %, the ground-only frame -2 %, one share of an 8-way 1080p
+//  frame -2.5 %, the 1080p frame +0.8 % (six interleaved rounds); 4: +17 ... +29 %.
+//  profiles/r02/j_ab_waves_per_simd_again.log)
 #ifndef RTX_SHADE_CUT_WAVES_PER_SIMD
-#define RTX_SHADE_CUT_WAVES_PER_SIMD 6
+#define RTX_SHADE_CUT_WAVES_PER_SIMD 8
 #endif
 template <bool COUNT, bool FAST, int NW, bool SPHERES, bool WHOLE>
 __global__ void __launch_bounds__(64 * NW, COUNT ? 1 : (WHOLE ? RTX_SHADE_WAVES_PER_SIMD : RTX_SHADE_CUT_WAVES_PER_SIMD))
@@ -1173,7 +1181,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
 #else
                         ShadowRay sr;
-                        if (full_tile) {   // chunk = light sample c0 / 64 of the tile's 64 pixels
+                        if (RTX_FULL_TILE_GENERAL && full_tile) {   // chunk = light sample c0 / 64 of the tile's 64 pixels
                             sr = shadow_ray_from(my_hit, l_light, true, lane, c0 >> 6);
                         } else {
                             const bool valid = c0 + lane < total;
@@ -1183,7 +1191,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
 #endif
                         const bool no_ground = have_plane &&
-                            (full_tile ? ballot(!plane_rules_out(plane0, my_plane, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull
+                            ((RTX_FULL_TILE_GENERAL && full_tile) ? ballot(!plane_rules_out(plane0, my_plane, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull
                                        : ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
                         // A chunk with nothing to walk — no subtree in the tile's cut, and the ground (the only global triangle)
                         // ruled out from its plane — is lit; what is left of the walk's own prologue is its refusal of hard
@@ -1209,7 +1217,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
 #endif
                         if (!ok && lane == 0) l_ctl[1] = 1u;
-                        if (grey_tile && full_tile) shadow_result_grey_from(my_hit, l_res, res_stride, sr, denom_d);
+                        if (RTX_FULL_TILE_GENERAL && grey_tile && full_tile) shadow_result_grey_from(my_hit, l_res, res_stride, sr, denom_d);
                         else if (grey_tile) shadow_result_grey<!WHOLE>(l_hit, l_res, res_stride, sr, denom_d);   // (whole-stream form: no registers to spare, +0.7 %)
                         else shadow_result(l_hit, l_res, res_stride, sr);
                     }
