@@ -928,8 +928,13 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
 #ifndef RTX_OPEN_GROUND_LOOP
 #define RTX_OPEN_GROUND_LOOP 1
 #endif
-#ifndef RTX_FULL_TILE_GENERAL      // 1: the general chunk loop, too, works on a full tile's registers
-#define RTX_FULL_TILE_GENERAL 1
+// 1: the general chunk loop, too, works on a full tile's registers (hit record, the origin's part of the ground's
+// certificate).  At the 64 vector registers of 8 wavefronts per SIMD that keeps nine of them alive across the walk and ten
+// in scratch; with the registers the open-ground loop's alone, one: big_bunny 4096x4096 -1.2 %, the ground-only frame
+// -1.7 %, one share of an 8-way 1080p frame -2.6 %, the 1080p frame +0.5 % (four interleaved rounds,
+// profiles/r02/j_ab_full_tile_registers.log).
+#ifndef RTX_FULL_TILE_GENERAL
+#define RTX_FULL_TILE_GENERAL 0
 #endif
 #ifndef RTX_FULL_TILE_PATH
 #define RTX_FULL_TILE_PATH 1
@@ -1106,7 +1111,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             const bool full_tile = RTX_FULL_TILE_PATH != 0 && !WHOLE && sample_major && n_hit == 64u;
             float my_hit[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             PlaneOrigin my_plane = {0.0f, 0.0f};          // the origin's part of the ground's certificate (plane_rules_out)
-            if (full_tile) {
+            if (RTX_FULL_TILE_GENERAL && full_tile) {
 #pragma unroll
                 for (uint32_t k = 0; k < 7u; ++k) my_hit[k] = l_hit[kHitStride * lane + k];
                 if (have_plane) my_plane = plane_origin(plane0, my_hit[0], my_hit[1], my_hit[2]);
@@ -1158,6 +1163,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     uint32_t c_first = wave * 64u;
 #if RTX_OPEN_GROUND_LOOP && !RTX_EXPERIMENT_NO_WALK && !RTX_EXPERIMENT_PAIR && !RTX_WIDE_WALK
                     if (!WHOLE && full_tile && grey_tile && n_cut == 0u && have_plane && S.n_global == 1u) {
+#if !RTX_FULL_TILE_GENERAL      // the registers are this loop's alone: loaded here, dead behind it
+#pragma unroll
+                        for (uint32_t k = 0; k < 7u; ++k) my_hit[k] = l_hit[kHitStride * lane + k];
+                        my_plane = plane_origin(plane0, my_hit[0], my_hit[1], my_hit[2]);
+#endif
                         for (; c_first < total; c_first += 64u * NW) {
                             const uint32_t sample = c_first >> 6;
                             const float *lp = l_light + 3u * sample;
