@@ -1174,7 +1174,9 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             const float vx = lp[0] - my_hit[0], vy = lp[1] - my_hit[1], vz = lp[2] - my_hit[2];   // p - orig
                             float dist_light, sx, sy, sz;
                             if (!length_and_direction(vx, vy, vz, dist_light, sx, sy, sz)) break;    // main.rs:201-202
-                            if (ballot(!plane_rules_out(plane0, my_plane, sx, sy, sz)) != 0ull) break;
+                            // (the certificate's "magnitude" half: these origins lie on the ground, "moving away" certifies
+                            //  none of them; a tile above the ground falls to the general loop and the whole certificate)
+                            if (ballot(!plane_magnitude(plane0, my_plane, sx, sy, sz)) != 0ull) break;
                             const float lnd = fabsf(my_hit[3] * sx + my_hit[4] * sy + my_hit[5] * sz);            // main.rs:207
                             l_res[__umul24(lane, res_stride) + sample] = div_denom(my_hit[6] * lnd, denom_d);      // main.rs:211
                         }
@@ -1324,8 +1326,16 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     }
                 } else {
                     uint32_t px, py, ly;
-                    if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly) && mine)
-                        store_pixel(S, l_thr, out, px, ly, l_pix[4u * lane], l_pix[4u * lane + 1u], l_pix[4u * lane + 2u]);
+                    if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly) && mine) {
+                        const float cr = l_pix[4u * lane], cg = l_pix[4u * lane + 1u], cb = l_pix[4u * lane + 2u];
+                        if (ballot(!(cr == cg && cg == cb)) == 0ull) {   // grey sums: one search of the thresholds, not three
+                            const uint8_t q = (uint8_t)quantise(l_thr, cr);
+                            uint8_t *p = out + ((size_t)ly * S.width + px) * 3u;             // put_pixel, main.rs:293-294
+                            p[0] = q; p[1] = q; p[2] = q;
+                        } else {
+                            store_pixel(S, l_thr, out, px, ly, cr, cg, cb);
+                        }
+                    }
                 }
             }
         }

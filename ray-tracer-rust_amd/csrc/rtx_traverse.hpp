@@ -711,6 +711,13 @@ __device__ __forceinline__ bool plane_rules_out(const TriRec &g, const PlaneOrig
     const bool away = po.sn * sd > 0.0f && fabsf(sd) > kd;
     return magnitude || away;
 }
+// (the "magnitude" half alone — all there is for an origin ON the plane, whose PlaneOrigin::sn is 0; for any other
+//  origin it certifies less, never more)
+__device__ __forceinline__ bool plane_magnitude(const TriRec &g, const PlaneOrigin &po, float dx, float dy, float dz)
+{
+    const float sd = __builtin_fmaf(dz, g.e1[2], __builtin_fmaf(dy, g.e1[1], dx * g.e1[0]));
+    return po.lhs < fabsf(sd) - g.bmin[0];
+}
 __device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float oy, float oz, float dx, float dy, float dz)
 {
     return plane_rules_out(g, plane_origin(g, ox, oy, oz), dx, dy, dz);
