@@ -385,6 +385,12 @@ constexpr uint32_t kChunkFixedCost = 8u;
 constexpr uint32_t kCutMaxNodes = 1u << 16;
 
 // independent wavefronts (tiles) per workgroup of probe_kernel: 1, 4 and 8 measured the same (m_ab_probewaves.log)
+// 1: probe_kernel's primary walk on the four-child form of the tree (measured: the scheduling pass of one share of an
+// 8-way 1080p frame 0.090 -> 0.087 ms, of the 1M-triangle soup 2.95 -> 2.80 ms, but big_bunny 4096x4096 0.294 -> 0.311 ms
+// and the ground-only frame 0.051 -> 0.054 ms: tiles that walk next to nothing pay for four boxes per step.  Off.)
+#ifndef RTX_PROBE_WIDE
+#define RTX_PROBE_WIDE 0
+#endif
 #ifndef RTX_PROBE_XCD
 #define RTX_PROBE_XCD 1
 #endif
@@ -645,12 +651,21 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     float dx, dy, dz;
     primary_ray(S, in_frame, px, py, r, dx, dy, dz);
     LaneRay pr = make_ray(in_frame, S.eye[0], S.eye[1], S.eye[2], dx, dy, dz);
-#if RTX_WIDE_WALK
+#if RTX_EXPERIMENT_PROBE_PHASES   // timing experiment only: a tile's primary walk and its cut's descent, 10 ns ticks, in the
+    const unsigned long long pp_t0 = wall_clock64();   // descriptor's spare word (low / high half); tools/probe_phases.py
+#endif
+#if RTX_WIDE_WALK || RTX_PROBE_WIDE
+    // (A/B builds: the PRIMARY walk on the four-child form of the tree, rtx_traverse.hpp: walk_wide.  A primary walk is one
+    //  wavefront's chain of dependent fetches, ~0.3 us per step, and the longest of them — a silhouette tile's, 42 us — is
+    //  the length of this pass for one GPU's share of a frame, tools/probe_phases.py; see RTX_PROBE_WIDE for what it gave.)
     const bool ok = hit_wide<COUNT, FAST, SPHERES, false>((const WideNode RTX_CONSTANT *)S.wide, S.n_wide, tris, S.shade, nullptr, 0u, pr, wc,
                                                           S.n_global, false);                                  // main.rs:187
     (void)nodes;
 #else
     const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
+#endif
+#if RTX_EXPERIMENT_PROBE_PHASES
+    const unsigned long long pp_t1 = wall_clock64();
 #endif
     const bool hit = ok && in_frame && pr.best_idx != kNone;
     const unsigned long long hit_mask = ballot(hit);
@@ -750,7 +765,12 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     if (lane == 0) {
         const bool count_it = !(flags & 2u);
         const uint32_t key = (sky || (flags & 2u)) ? kNone : cost_class(cost);
-#if RTX_EXPERIMENT_TIMELINE || RTX_EXPERIMENT_PHASES
+#if RTX_EXPERIMENT_PROBE_PHASES
+        const unsigned long long pp_t2 = wall_clock64();
+        const uint32_t walk_ticks = (uint32_t)(pp_t1 - pp_t0) > 0xFFFFu ? 0xFFFFu : (uint32_t)(pp_t1 - pp_t0);
+        const uint32_t rest_ticks = (uint32_t)(pp_t2 - pp_t1) > 0xFFFFu ? 0xFFFFu : (uint32_t)(pp_t2 - pp_t1);
+        W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), walk_ticks | (rest_ticks << 16)};
+#elif RTX_EXPERIMENT_TIMELINE || RTX_EXPERIMENT_PHASES
         W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), 0u};   // spare word: the tile's jobs add their durations
 #else
         W.tiles[tile_id] = TileDesc{key, n_hit, flags | (n_cut << kTileCutShift), counted + (count_it ? n_hit : 0u)};
