@@ -5,6 +5,7 @@
 //! compares every offset and size with what a C compiler reports for include/rtx.h (integration/layout.json is the
 //! table both sides must equal).  Edit the header, this file and the table together.
 #![allow(dead_code)]
+use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const RTX_ABI_VERSION: c_int = 3;
@@ -117,7 +118,7 @@ pub fn check(rc: c_int) -> Result<(), String> {
     if rc == RTX_OK {
         Ok(())
     } else {
-        let text = unsafe { std::ffi::CStr::from_ptr(rtx_strerror(rc)) };
+        let text = unsafe { CStr::from_ptr(rtx_strerror(rc)) };
         Err(format!("librtx: {} [{}]", text.to_string_lossy(), rc))
     }
 }
