@@ -132,7 +132,7 @@ int upload_all(RtxScene *scene, DeviceState &st)
     int rc;
     const float inflate = RTX_CULL_INFLATED ? p.cull_delta : 0.0f;
     if ((rc = upload_vec(&st.nodes, rtx::nodes_in_device_order(p.nodes, inflate), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
-    {   // the wide nodes' boxes move outwards like the binary stream's (cull_delta)
+    if (!p.wide.empty()) {   // A/B builds only (scene_prep.h: kBuildWideTree); boxes moved outwards like the binary stream's
         std::vector<rtx::WideNode> w = p.wide;
         for (rtx::WideNode &n : w)
             for (int c = 0; c < 4; ++c)

@@ -19,7 +19,7 @@ namespace rtx {
 // Passed by value (kernarg segment -> SGPRs).
 struct DeviceScene {
     const NodeRec  *nodes;         // (n_nodes + 1) x 32 B, pre-order with skip links; last = zeroed sentinel
-    const WideNode *wide;          // n_wide x 128 B: the same tree with four children per node, what the walks run on (root first)
+    const WideNode *wide;          // A/B builds only (scene_prep.h: kBuildWideTree), else NULL: n_wide x 128 B, the tree with four children per node
     const NodeRec  *ref_nodes;     // (n_ref_nodes + 1) x 32 B: the reference's own tree, or NULL
     const TriRec   *tris;          // n_tris x 64 B, leaf order
     const ShadeRec *shade;         // n_tris x 32 B, caller order
@@ -89,9 +89,7 @@ struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc
 #endif
 // 1: the kernels walk the four-child form of the tree (rtx_traverse.hpp: walk_wide) instead of the binary stream.  Same
 // bytes, measured slower on every configuration: kept as a build switch for A/B runs only.
-#ifndef RTX_WIDE_WALK
-#define RTX_WIDE_WALK 0
-#endif
+// (RTX_WIDE_WALK: default 0 in scene_prep.h, which also decides whether the four-child tree is built at all)
 constexpr uint32_t kMaxCut = RTX_MAX_CUT;    // <= 64: one wavefront holds the whole frontier of the cut's descent
 constexpr uint32_t kTileCutShift = 8u;       // TileDesc::flags
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);

@@ -723,6 +723,134 @@ __device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float
     return plane_rules_out(g, plane_origin(g, ox, oy, oz), dx, dy, dz);
 }
 
+// ---- the box records of a walk, by hand ---------------------------------------------------------------------------------
+// A walk is a chain of dependent steps — fetch a record, test its box, vote, choose the successor — and what bounds it is
+// the scalar unit (one per compute unit, shared by 32 wavefronts) as much as the vector units: the compiler's step is 15
+// scalar instructions per record beside 16 vector ones (round 2's ISA), several of them conversions between a vote and an
+// integer and back.  advance_to_leaf is the part of the walk that only looks at boxes, written out: from record `off` (a
+// BYTE offset into the stream) it steps until it stands on a LEAF whose box some walking lane passes, or reaches `end`.
+// Per record: s_load_dwordx8, s_waitcnt, s_add (the next record's offset; also the wait state between the scalar load and
+// the vector instructions that read it), sixteen vector instructions (the same ones, in the same order, as box_mask's
+// inflated-plane form), two s_and_b64 (the second one's SCC is "some walking lane passes"), then
+//     nobody passes   s_cbranch_scc0, s_lshl (skip link -> bytes), s_cmp (leaf?), s_cselect, s_cmp (end?), s_cbranch   = 11
+//     inner, passed   s_cbranch_scc0 (not taken), s_cmp (leaf?), s_cbranch (not taken), s_mov, s_branch              = 10
+// Leaves are handed back to C++ (leaf_triangles): their primitive tests, the candidates' own boxes and the any-hit rule
+// are per-lane work whose rare paths (exact divisions, square roots) the compiler writes better than I would.
+// The record lives in FIXED scalar registers, s[64:71]: an inline-assembly operand that is a register tuple cannot be
+// taken apart inside the assembly text, and the steps need words 0-5 as vector operands and 6, 7 on the scalar unit.
+// On return: info = the leaf's info word (bit 31 set) and link = its record count, off = the leaf's offset — or info = 0
+// and off >= end.  `visits` counts the records fetched (COUNT builds only).
+#ifndef RTX_ASM_WALK
+#define RTX_ASM_WALK 1
+#endif
+template <bool COUNT>
+__device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__restrict__ nodes, uint32_t &off, uint32_t end,
+                                                unsigned long long alive, const LaneRay &r, uint32_t &link, uint32_t &info,
+                                                uint32_t &visits)
+{
+    float a, b, c, d, e, f, g;
+    unsigned long long m;
+    uint32_t nxt, skip;
+    uint32_t o = off, w6, w7, n = visits;
+    const float px = -r.nx, py = -r.ny, pz = -r.nz;   // o * (1/d): the ray keeps these; the step subtracts by operand modifier
+#define RTX_ADVANCE_BODY(COUNT_LINE)                                                                                      \
+        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                 \
+        "s_cbranch_scc0 .Lend%=\n"                                                                                        \
+        ".Lloop%=:\n\t"                                                                                                   \
+        "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"                                                                    \
+        COUNT_LINE                                                                                                        \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                        \
+        "s_add_u32 %[nxt], %[off], 32\n\t"                                                                                \
+        "v_fma_f32 %[a], s64, %[ix], -%[px]\n\t"   /* lo.x */                                                              \
+        "v_fma_f32 %[b], s66, %[ix], -%[px]\n\t"   /* hi.x */                                                              \
+        "v_fma_f32 %[c], s65, %[iy], -%[py]\n\t"   /* lo.y */                                                              \
+        "v_fma_f32 %[d], s67, %[iy], -%[py]\n\t"   /* hi.y */                                                              \
+        "v_fma_f32 %[e], s68, %[iz], -%[pz]\n\t"   /* lo.z */                                                              \
+        "v_fma_f32 %[f], s69, %[iz], -%[pz]\n\t"   /* hi.z */                                                              \
+        "v_min_f32 %[g], %[a], %[b]\n\t"                                                                                  \
+        "v_max_f32 %[a], %[a], %[b]\n\t"                                                                                  \
+        "v_min_f32 %[b], %[c], %[d]\n\t"                                                                                  \
+        "v_max_f32 %[c], %[c], %[d]\n\t"                                                                                  \
+        "v_min_f32 %[d], %[e], %[f]\n\t"                                                                                  \
+        "v_max_f32 %[e], %[e], %[f]\n\t"                                                                                  \
+        "v_max3_f32 %[g], %[g], %[b], %[d]\n\t"   /* entry */                                                             \
+        "v_min3_f32 %[a], %[a], %[c], %[e]\n\t"   /* exit */                                                              \
+        "v_cmp_ngt_f32 vcc, %[g], %[a]\n\t"       /* !(entry > exit): a NaN can only accept */                            \
+        "v_cmp_ngt_f32 %[m], 0, %[a]\n\t"         /* !(exit < 0) */                                                       \
+        "s_and_b64 vcc, vcc, %[m]\n\t"                                                                                    \
+        "s_and_b64 vcc, vcc, %[alive]\n\t"        /* SCC = some walking lane passes */                                    \
+        "s_cbranch_scc0 .Lnone%=\n\t"                                                                                     \
+        "s_cmp_lt_i32 s71, 0\n\t"                                                                                         \
+        "s_cbranch_scc1 .Lout%=\n\t"              /* a leaf to visit */                                                   \
+        "s_mov_b32 %[off], %[nxt]\n\t"            /* into the subtree: the next record (always inside the range) */       \
+        "s_branch .Lloop%=\n"                                                                                             \
+        ".Lnone%=:\n\t"                                                                                                   \
+        "s_lshl_b32 %[skip], s70, 5\n\t"                                                                                  \
+        "s_cmp_lt_i32 s71, 0\n\t"                                                                                         \
+        "s_cselect_b32 %[off], %[nxt], %[skip]\n\t" /* behind a leaf: the next record; else: behind the subtree */        \
+        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                 \
+        "s_cbranch_scc1 .Lloop%=\n"                                                                                       \
+        ".Lend%=:\n\t"                                                                                                    \
+        "s_mov_b32 s71, 0\n"                                                                                              \
+        ".Lout%=:"
+    if (COUNT) {
+        asm volatile(RTX_ADVANCE_BODY("s_add_u32 %[n], %[n], 1\n\t")
+                     : [off] "+s"(o), [n] "+s"(n), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
+                       [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
+                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz),
+                       [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
+                     : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69");
+    } else {
+        asm volatile(RTX_ADVANCE_BODY("")
+                     : [off] "+s"(o), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
+                       [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
+                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz),
+                       [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
+                     : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69");
+    }
+#undef RTX_ADVANCE_BODY
+    // The statement above returns scalar AND vector registers, so the compiler's value for "everything it returns" is a
+    // divergent one, and a member of it that is first read in ANOTHER basic block gets a vector register whatever its own
+    // constraint says (ROCm 7.2: the cross-block register of an aggregate takes the aggregate's divergence) — the offset
+    // then comes back into the next turn's "+s" operand as an illegal vector-to-scalar copy.  Passing the scalar results
+    // through a statement of their own, with scalar results only, in the same block, pins them: it emits nothing.
+    asm volatile("" : "+s"(o), "+s"(w6), "+s"(w7), "+s"(n));
+    off = o;
+    link = w6;
+    info = w7;
+    visits = n;
+}
+
+// The walk over the records [i, end) with the multiply-based test, its box records stepped by advance_to_leaf; what
+// walk_range<.., USE_FAST = true> does, record for record.
+template <bool COUNT, bool SPHERES, bool ANYHIT>
+__device__ __forceinline__ unsigned long long walk_range_fast(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                                              const TriRec RTX_CONSTANT *__restrict__ tris,
+                                                              const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
+                                                              LaneRay &r, unsigned long long alive,
+                                                              unsigned long long &n_active, WaveCounters &wc)
+{
+    uint32_t off = i << 5;
+    const uint32_t end_off = end << 5;
+    for (;;) {
+        uint32_t link, info, visits = 0u;
+        advance_to_leaf<COUNT>(nodes, off, end_off, alive, r, link, info, visits);
+        if (COUNT) { wc.box_tests += n_active * visits; wc.node_visits += visits; }
+        if (info == 0u) break;
+        if (SPHERES && (info & kSphereFlag))
+            leaf_spheres<COUNT, ANYHIT>(tris, shade, info & kLeafIndexMask, link, r, n_active, wc);
+        else
+            leaf_triangles<COUNT, ANYHIT, true>(tris, shade, info & kLeafIndexMask, link, r, alive, n_active, wc);
+        if (ANYHIT) {   // lanes that found an occluder have left the walk; so does a wavefront without lanes
+            alive = ballot(r.active);
+            if (alive == 0ull) break;
+            if (COUNT) n_active = __popcll(alive);
+        }
+        off += 32u;
+    }
+    return alive;
+}
+
 // The walk itself over the records [i, end) of the stream, for one kind of box test (USE_FAST: the multiply-based
 // conservative test, else the exact one).  Returns the lanes still walking (any-hit walks: the others found their
 // occluder); a wavefront without such lanes leaves the range at once.
@@ -733,6 +861,9 @@ __device__ __forceinline__ unsigned long long walk_range(const NodeRec RTX_CONST
                                                          LaneRay &r, unsigned long long alive,
                                                          unsigned long long &n_active, WaveCounters &wc)
 {
+#if RTX_ASM_WALK && RTX_CULL_FMA && RTX_CULL_INFLATED && !RTX_CULL_PACKED
+    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc);
+#endif
     while (i < end) {
 #if RTX_ASM_NODE_LOAD
         const NodeRec cur = load_node_at(nodes, i);
@@ -853,8 +984,9 @@ __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__
     return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
 }
 
-// ---- the wide walk ---------------------------------------------------------------------------------------------------
-// What the kernels run: the same tree with FOUR children per node (scene_prep.h: WideNode).  A step fetches one
+// ---- the wide walk (A/B builds only: -DRTX_WIDE_WALK=1 / -DRTX_PROBE_WIDE=1; librtx.so walks the binary stream) -------
+// Measured slower than the binary walk in every form that was tried, kept for comparison.
+// The same tree with FOUR children per node (scene_prep.h: WideNode).  A step fetches one
 // 128-byte node with two scalar loads, tests its four child boxes in one stretch of vector code, votes once per child
 // and then handles the children whose vote is not empty: a leaf child's primitives are tested on the spot, an inner
 // child goes onto the wave's stack — the 64 lanes of ONE vector register, written and read by lane number, so a push

@@ -679,15 +679,18 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             s.shade[i].rank = d.tie_rank ? d.tie_rank[i] : (want_ref ? ref_rank[i] : i);
 
         // after a tree is built: inner nodes of the library's stream name their second child in `info` (the first one
-        // is the next record; the binary walks only look at bit 31 of an inner node's info), and the tree proper (behind
-        // the root and the global triangles' leaf when there are any) is restated with four children per node — what
-        // the kernels walk
+        // is the next record; the walks only look at bit 31 of an inner node's info, the cut's descent follows both).
+        // A/B builds (kBuildWideTree) also restate the tree proper — behind the root and the global triangles' leaf when
+        // there are any — with four children per node.
         auto finish_tree = [&]() {
             for (size_t i = 0; i < s.nodes.size(); ++i)
                 if (!(s.nodes[i].info & kLeafFlag)) {
                     const NodeRec &first = s.nodes[i + 1];
                     s.nodes[i].info = (first.info & kLeafFlag) ? static_cast<uint32_t>(i) + 2u : first.link;
                 }
+            s.wide.clear();
+            s.wide_depth = 0;
+            if (!kBuildWideTree) return;
             const uint32_t proper = s.n_global != 0u ? 2u : 0u;
             std::vector<float> order_boxes(6 * static_cast<size_t>(n_prims));     // primitive boxes in leaf order
             for (uint32_t i = 0; i < n_prims; ++i) {
@@ -804,7 +807,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             };
             build_tree(64u);
             finish_tree();
-            if (s.wide_depth > kMaxWideDepth) {
+            if (kBuildWideTree && s.wide_depth > kMaxWideDepth) {
                 // the walk's stack holds 3 pending children per wide level: a tree that deep (a pathological scene) is
                 // rebuilt balanced, which halves its levels when the children are pulled up
                 uint32_t halvings = 0;
@@ -814,8 +817,10 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                 if (s.wide_depth > kMaxWideDepth) return RTX_ERR_INTERNAL;
             }
         }
-        if (static_cast<uint64_t>(s.wide.size()) * sizeof(WideNode) >= (1ull << 31)) return RTX_ERR_UNSUPPORTED;
-        if (s.wide_depth > kMaxWideDepth) return RTX_ERR_INTERNAL;     // (RTX_ACCEL_BRUTE: log4(n / 16) levels)
+        if (kBuildWideTree) {
+            if (static_cast<uint64_t>(s.wide.size()) * sizeof(WideNode) >= (1ull << 31)) return RTX_ERR_UNSUPPORTED;
+            if (s.wide_depth > kMaxWideDepth) return RTX_ERR_INTERNAL;     // (RTX_ACCEL_BRUTE: log4(n / 16) levels)
+        }
         s.tris.resize(n_prims);
         std::vector<uint32_t> pos_of(n_prims);
         for (uint32_t i = 0; i < n_prims; ++i) {

@@ -47,7 +47,18 @@ inline std::vector<NodeDev> nodes_in_device_order(const std::vector<NodeRec> &v,
                          v[i].bmin[2] - inflate, v[i].bmax[2] + inflate, v[i].link, v[i].info};
     return out;
 }
-// One WIDE node of the walk the kernels run: four children tested per step, 32 dwords, fetched with two scalar 64-byte
+// The four-child form of the tree exists in A/B builds only (-DRTX_WIDE_WALK=1: every walk on it; -DRTX_PROBE_WIDE=1:
+// probe_kernel's primary walk): measured slower than the binary stream on every configuration.
+// librtx.so neither builds nor uploads it, and none of its limits (depth, 25-bit record index) binds the product.
+#ifndef RTX_WIDE_WALK
+#define RTX_WIDE_WALK 0
+#endif
+#ifndef RTX_PROBE_WIDE
+#define RTX_PROBE_WIDE 0
+#endif
+constexpr bool kBuildWideTree = (RTX_WIDE_WALK != 0) || (RTX_PROBE_WIDE != 0);
+
+// One WIDE node (A/B builds, see above): four children tested per step, 32 dwords, fetched with two scalar 64-byte
 // loads.  Made from the binary tree above by pulling grandchildren up (wide_nodes_build), so every child box is the box
 // of a binary node (or of a run of a large leaf's primitives) — a superset chain over the same exact leaf boxes — and
 // the walk keeps its pending children on a small wave-uniform stack.
@@ -106,8 +117,8 @@ struct PreparedScene {
     uint32_t n_spheres = 0;            // of which spheres
     uint32_t n_samples = 0;
     std::vector<NodeRec>  nodes;
-    std::vector<WideNode> wide;        // the same tree with four children per node: what the kernels walk (may be empty:
-                                       // a scene of global triangles only); wide[0] is the root
+    std::vector<WideNode> wide;        // A/B builds only (kBuildWideTree): the same tree with four children per node (may be
+                                       // empty: a scene of global triangles only); wide[0] is the root.  Else empty.
     uint32_t wide_depth = 0;           // levels of wide nodes
     std::vector<NodeRec>  ref_nodes;   // the reference's own tree as a stream (empty when not built)
     std::vector<TriRec>   tris;        // primitive records (triangles and spheres) in leaf order
@@ -130,7 +141,8 @@ struct PreparedScene {
     std::vector<TriRec>   global_planes;
 };
 constexpr uint32_t kMaxGlobalPrims = 8u;
-constexpr uint64_t kMaxPrimitives = 1ull << 25;   // a wide leaf ref holds a 25-bit record index (64 B x 2^25 = 2 GiB of records)
+// the walk addresses primitive records by 32-bit byte offsets, 64 B each; an A/B build's wide leaf ref holds a 25-bit index
+constexpr uint64_t kMaxPrimitives = kBuildWideTree ? (1ull << 25) : (1ull << 26);
 
 // Returns RTX_OK or a negative RtxError.
 int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);

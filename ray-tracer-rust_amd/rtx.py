@@ -16,8 +16,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # librtx.so is the product.  RTX_PY_ABLATION=1 makes THIS BINDING load librtx_ablation.so instead (the same sources
 # built with -DRTX_ABLATION=1: every earlier kernel form, selectable through RTX_VARIANT) — for tools/ and the
-# variant-equality test only; the library itself reads no environment variable.
-LIB_PATH = os.path.join(_HERE, "librtx_ablation.so" if os.environ.get("RTX_PY_ABLATION") == "1" else "librtx.so")
+# variant-equality test only; the library itself reads no environment variable.  RTX_PY_LIB=<path> makes this binding
+# load a library built somewhere else (tools/ab_build.sh: A/B variants live under gpurun_out/ and never replace the
+# product's file).
+LIB_PATH = os.environ.get("RTX_PY_LIB") or os.path.join(
+    _HERE, "librtx_ablation.so" if os.environ.get("RTX_PY_ABLATION") == "1" else "librtx.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -55,7 +55,7 @@ int main(int argc, char **argv)
     CHECK(orc_import_obj((root + "/models/bunny.obj").c_str(), &ot) == 4968);
     orc_free(ot);
 
-    // --- the scene main() builds: mesh + ground, prepared for the device (trees, wide nodes, light points, thresholds)
+    // --- the scene main() builds: mesh + ground, prepared for the device (trees, light points, thresholds)
     const float ground[9] = {-10000, 0, -10000, 10000, 0, -10000, 0, 0, 10000};
     tris.insert(tris.end(), ground, ground + 9);
     std::vector<float> rgb(3 * static_cast<size_t>(n), 1.0f);
@@ -64,7 +64,7 @@ int main(int argc, char **argv)
         RtxSceneDesc d = default_desc(64, 48, tris, rgb, samples);
         rtx::PreparedScene s;
         CHECK(rtx::prepare_scene(d, s) == RTX_OK);
-        CHECK(s.n_global == 1 && !s.wide.empty() && s.wide_depth >= 1 && s.ref_nodes.size() == 2u * 4969u - 1u);
+        CHECK(s.n_global == 1 && s.wide.empty() == !rtx::kBuildWideTree && s.ref_nodes.size() == 2u * 4969u - 1u);
         d.accel = RTX_ACCEL_BRUTE; d.reference_tree = RTX_REFTREE_NEVER;
         rtx::PreparedScene b;
         CHECK(rtx::prepare_scene(d, b) == RTX_OK && b.nodes.size() == 1);
