@@ -141,7 +141,8 @@ int upload_all(RtxScene *scene, DeviceState &st)
     }
     if (!p.ref_nodes.empty() &&
         (rc = upload_vec(&st.ref_nodes, rtx::nodes_in_device_order(p.ref_nodes), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
-    if ((rc = upload_vec(&st.tris, p.tris)) != RTX_OK) return rc;
+    // one record of zeros behind the primitive records: a leaf's loop touches the record after the one it tests (load_tri_at)
+    if ((rc = upload_vec(&st.tris, p.tris, sizeof(rtx::TriRec))) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.shade, p.shade)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.samples, p.samples)) != RTX_OK) return rc;
     if ((rc = upload_vec(&st.lights, p.light_points)) != RTX_OK) return rc;

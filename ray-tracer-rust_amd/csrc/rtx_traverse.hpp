@@ -511,12 +511,25 @@ __device__ __forceinline__ bool length_and_direction(float vx, float vy, float v
 #ifndef RTX_ASM_TRI_LOAD
 #define RTX_ASM_TRI_LOAD 1
 #endif
+// RTX_TRI_TOUCH_NEXT: with the record, one word of the NEXT record is requested (and thrown away): a leaf tests its
+// records one after another, each a dependent fetch of a line of its own, and in a scene whose records do not fit the
+// L2s (BASELINE configs[4]) each of them is a miss of several hundred cycles; this way the next one is on its way — into
+// L2 and the scalar cache — while the current one is tested.  The array has one spare record at its end (rtx_api.cpp).
+#ifndef RTX_TRI_TOUCH_NEXT
+#define RTX_TRI_TOUCH_NEXT 1
+#endif
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ TriRec load_tri_at(const TriRec RTX_CONSTANT *base, uint32_t index)
 {
     u32x16 v;
     const uint32_t byte_offset = index << 6;
+#if RTX_TRI_TOUCH_NEXT
+    uint32_t touched;
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dword %1, %2, %3 offset:0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v), "=&s"(touched) : "s"(base), "s"(byte_offset));
+#else
     asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byte_offset));
+#endif
     TriRec t;
     t.v0[0] = __uint_as_float(v[0]); t.v0[1] = __uint_as_float(v[1]); t.v0[2] = __uint_as_float(v[2]);
     t.e1[0] = __uint_as_float(v[3]); t.e1[1] = __uint_as_float(v[4]); t.e1[2] = __uint_as_float(v[5]);

@@ -289,8 +289,8 @@ public:
     // depth_cap: levels the tree may have.  A range that could not be finished within the cap by halving is halved
     // from there on (median split along its widest centroid axis) instead of split by the SAH.
     TreeBuilder(std::vector<Prim> &prims, std::vector<NodeRec> &nodes, uint32_t leaf_max, double box_cost,
-                uint32_t depth_cap = 64u)
-        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost), depth_cap_(depth_cap) {}
+                uint32_t depth_cap = 64u, const float *light = nullptr)
+        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost), depth_cap_(depth_cap), light_(light) {}
 
     uint32_t leaves = 0, max_leaf = 0, depth = 0;
 
@@ -345,9 +345,29 @@ public:
             if (count > max_leaf) max_leaf = count;
             return;
         }
+        if (light_) mid = lightward_second(begin, mid, end);
         build(begin, mid, level + 1);
         build(mid, end, level + 1);
         nodes_[self].link = static_cast<uint32_t>(nodes_.size());
+    }
+
+    // Which child comes first in the stream is free (the walks visit every box that passes; closest hits take a minimum,
+    // shadow rays any occluder).  With a light position given, the child whose primitives lie NEARER the light goes second:
+    // a walk then meets the far side of every split first, which is where the shadow rays of the lit surfaces below and
+    // around a mesh enter it (measured: the 1M-triangle soup -1.5 %, 3.5 % fewer box records; profiles/r03).
+    uint32_t lightward_second(uint32_t begin, uint32_t mid, uint32_t end)
+    {
+        auto mean_dist2 = [&](uint32_t a, uint32_t b) {
+            double c[3] = {0, 0, 0};
+            for (uint32_t i = a; i < b; ++i)
+                for (int k = 0; k < 3; ++k) c[k] += prims_[i].c[k];
+            double d2 = 0;
+            for (int k = 0; k < 3; ++k) { const double d = c[k] / double(b - a) - light_[k]; d2 += d * d; }
+            return d2;
+        };
+        if (!(mean_dist2(begin, mid) < mean_dist2(mid, end))) return mid;     // the first child is the farther one already
+        std::rotate(prims_.begin() + begin, prims_.begin() + mid, prims_.begin() + end);
+        return begin + (end - mid);
     }
 
 private:
@@ -416,6 +436,7 @@ private:
     uint32_t leaf_max_;
     double box_cost_;
     uint32_t depth_cap_;
+    const float *light_;   // NULL: children in the order the split made them
 };
 
 }  // namespace
@@ -770,9 +791,21 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                     s.n_global = static_cast<uint32_t>(n);
                 }
             }
+            // centre of the light points (the first primary ray's): orders the children of every node (TreeBuilder)
+            float light_c[3] = {0.0f, 0.0f, 0.0f};
+            bool light_ok = RTX_LIGHTWARD_ORDER != 0 && d.nb_light_sample != 0u;
+            if (light_ok) {
+                double acc[3] = {0, 0, 0};
+                for (uint32_t i = 0; i < d.nb_light_sample; ++i)
+                    for (int k = 0; k < 3; ++k) acc[k] += s.light_points[3 * static_cast<size_t>(i) + k];
+                for (int k = 0; k < 3; ++k) {
+                    light_c[k] = static_cast<float>(acc[k] / d.nb_light_sample);
+                    light_ok = light_ok && std::isfinite(light_c[k]);
+                }
+            }
             auto build_tree = [&](uint32_t depth_cap) {
                 s.nodes.clear();
-                TreeBuilder tb(prims, s.nodes, leaf_max, box_cost, depth_cap);
+                TreeBuilder tb(prims, s.nodes, leaf_max, box_cost, depth_cap, light_ok ? light_c : nullptr);
                 if (s.n_global) {
                     Box g;
                     g.reset();

@@ -106,6 +106,10 @@ struct ShadeRec {
     float    rgb[3];      // Color
     uint32_t kind;        // 0 triangle, 1 sphere
 };
+// 1: the builder orders the children of every node far-from-the-light first (scene_prep.cpp: lightward_second)
+#ifndef RTX_LIGHTWARD_ORDER
+#define RTX_LIGHTWARD_ORDER 1
+#endif
 static_assert(sizeof(ShadeRec) == 32, "ShadeRec must be 32 bytes");
 
 struct PreparedScene {

@@ -41,6 +41,15 @@ for a, b in zip(edges[:-1], edges[1:]):
     if m.any():
         print("cut %2d..%2d: %6d tiles  %8.0f us total (%4.1f %%)  mean %7.2f us  max %7.2f us  mean hits %4.1f" % (
             a, b - 1, int(m.sum()), us[m].sum(), 100 * us[m].sum() / us.sum(), us[m].mean(), us[m].max(), n_hit[m].mean()))
+# by ray numbering (bit 0 of the flags: sample-major = all 64 hit pixels on one primitive) and by duration
+for name, m0 in (("sample-major (one surface)", work & ((flags & 1) != 0)), ("pixel-major (mixed)", work & ((flags & 1) == 0))):
+    if not m0.any():
+        continue
+    print("%s: %d tiles, %.0f us total (%.1f %%), mean %.1f us" % (name, int(m0.sum()), us[m0].sum(), 100 * us[m0].sum() / us.sum(), us[m0].mean()))
+    for a, b in ((0, 30), (30, 60), (60, 120), (120, 250), (250, 500), (500, 1000), (1000, 1e9)):
+        m = m0 & (us >= a) & (us < b)
+        if m.any():
+            print("    %5.0f..%5.0f us: %7d tiles  %9.0f us (%4.1f %% of the frame)" % (a, min(b, 99999), int(m.sum()), us[m].sum(), 100 * us[m].sum() / us.sum()))
 top = np.argsort(-us)[:8]
 tx = (W + 7) // 8
 def tile_xy(t):   # the library numbers tiles by 8 x 8 blocks (rtx_kernel.hip: tile_xy)
