@@ -1191,12 +1191,19 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // ground-only frame, 81 % of big_bunny 4096x4096.
                     uint32_t c_first = wave * 64u;
 #if RTX_OPEN_GROUND_LOOP && !RTX_EXPERIMENT_NO_WALK && !RTX_EXPERIMENT_PAIR && !RTX_WIDE_WALK
-                    if (!WHOLE && full_tile && grey_tile && n_cut == 0u && have_plane && S.n_global == 1u) {
+                    if (!WHOLE && full_tile && grey_tile && n_cut == 0u && have_plane && S.n_global == 1u && denom_d.usable) {
 #if !RTX_FULL_TILE_GENERAL      // the registers are this loop's alone: loaded here, dead behind it
 #pragma unroll
                         for (uint32_t k = 0; k < 7u; ++k) my_hit[k] = l_hit[kHitStride * lane + k];
                         my_plane = plane_origin(plane0, my_hit[0], my_hit[1], my_hit[2]);
 #endif
+                        // The four words of the plane record this loop reads, as values of their own: the record came in with
+                        // one eight-word scalar load, the register allocator treats it as one eight-register value, and when
+                        // it spills that value around the walk (any change to the walk's registers decides that) this loop
+                        // reloads all eight words per chunk.  (The empty statement makes the copies opaque to the compiler.)
+                        float pn0 = plane0.e1[0], pn1 = plane0.e1[1], pn2 = plane0.e1[2], pkd = plane0.bmin[0];
+                        float dd_ = uniform(denom_d.d), dy_ = uniform(denom_d.y);   // (formed by vector instructions: same in every lane)
+                        asm volatile("" : "+s"(pn0), "+s"(pn1), "+s"(pn2), "+s"(pkd), "+s"(dd_), "+s"(dy_));
                         for (; c_first < total; c_first += 64u * NW) {
                             const uint32_t sample = c_first >> 6;
                             const float *lp = l_light + 3u * sample;
@@ -1205,9 +1212,17 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             if (!length_and_direction(vx, vy, vz, dist_light, sx, sy, sz)) break;    // main.rs:201-202
                             // (the certificate's "magnitude" half: these origins lie on the ground, "moving away" certifies
                             //  none of them; a tile above the ground falls to the general loop and the whole certificate)
-                            if (ballot(!plane_magnitude(plane0, my_plane, sx, sy, sz)) != 0ull) break;
+                            const float sd = __builtin_fmaf(sz, pn2, __builtin_fmaf(sy, pn1, sx * pn0));           // plane_magnitude
+                            if (ballot(!(my_plane.lhs < fabsf(sd) - pkd)) != 0ull) break;
                             const float lnd = fabsf(my_hit[3] * sx + my_hit[4] * sy + my_hit[5] * sz);            // main.rs:207
-                            l_res[__umul24(lane, res_stride) + sample] = div_denom(my_hit[6] * lnd, denom_d);      // main.rs:211
+                            // main.rs:211 by div_denom's short steps (the loop is entered with a usable divisor; a chunk with
+                            // a numerator outside their range is the general loop's — no loop-invariant flag is tested here:
+                            // as lane masks in spilled scalar registers two of them cost four reloads per chunk)
+                            const float x = my_hit[6] * lnd;
+                            if (ballot(!(x == 0.0f || x >= 0x1p-60f)) != 0ull) break;
+                            const float q0 = x * dy_;
+                            const float q1 = __builtin_fmaf(__builtin_fmaf(-dd_, q0, x), dy_, q0);
+                            l_res[__umul24(lane, res_stride) + sample] = __builtin_fmaf(__builtin_fmaf(-dd_, q1, x), dy_, q1);
                         }
                     }
 #endif

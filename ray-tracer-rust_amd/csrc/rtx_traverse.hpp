@@ -737,16 +737,29 @@ __device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float
 }
 
 // ---- the box records of a walk, by hand ---------------------------------------------------------------------------------
-// A walk is a chain of dependent steps — fetch a record, test its box, vote, choose the successor — and what bounds it is
-// the scalar unit (one per compute unit, shared by 32 wavefronts) as much as the vector units: the compiler's step is 15
-// scalar instructions per record beside 16 vector ones (round 2's ISA), several of them conversions between a vote and an
-// integer and back.  advance_to_leaf is the part of the walk that only looks at boxes, written out: from record `off` (a
-// BYTE offset into the stream) it steps until it stands on a LEAF whose box some walking lane passes, or reaches `end`.
-// Per record: s_load_dwordx8, s_waitcnt, s_add (the next record's offset; also the wait state between the scalar load and
-// the vector instructions that read it), sixteen vector instructions (the same ones, in the same order, as box_mask's
-// inflated-plane form), two s_and_b64 (the second one's SCC is "some walking lane passes"), then
-//     nobody passes   s_cbranch_scc0, s_lshl (skip link -> bytes), s_cmp (leaf?), s_cselect, s_cmp (end?), s_cbranch   = 11
-//     inner, passed   s_cbranch_scc0 (not taken), s_cmp (leaf?), s_cbranch (not taken), s_mov, s_branch              = 10
+// A walk is a chain of dependent steps — fetch a record, test its box, vote, choose the successor.  The compiler's step
+// is 15 scalar instructions per record beside 16 vector ones (round 2's ISA), several of them conversions between a vote
+// and an integer and back.  advance_to_leaf is the part of the walk that only looks at boxes, written out: from record
+// `off` (a BYTE offset into the stream) it steps until it stands on a LEAF whose box some walking lane passes, or reaches
+// `end`.
+//
+// Per record, scalar: s_load_dwordx8, s_waitcnt, s_add (the next record's offset; also the wait state between the scalar
+// load and the vector instructions that read it), s_and_b64 with the walking lanes (its SCC is "somebody passes"), then
+//     nobody passes   s_cbranch_scc0, s_lshl (skip link -> bytes), s_cmp (leaf?), s_cselect, s_cmp (end?), s_cbranch   = 10
+//     inner, passed   s_cbranch_scc0 (not taken), s_cmp (leaf?), s_cbranch (not taken), s_mov, s_branch              =  9
+// Per record, vector: box_mask's inflated-plane test.  In general form that is six fused multiply-adds (a plane's
+// distance along the ray), three min / three max (which plane of an axis is the near one depends on the lane's direction
+// sign), max3 / min3 (entry, exit) and the comparisons: sixteen.  When every WALKING lane's direction has the same signs
+// — `oct`: bit a set = component a negative; the sixty-four rays of a chunk run from neighbouring points to one light
+// point, or from one point to the light's few units — the near plane of an axis is the same WORD of the record for all
+// of them, and the step is written for that octant: near and far distances straight from the right words, no min / max,
+// and the "exit not behind the origin" test folded into the entry (max(entry, 0) <= exit): ten.  For a lane of the
+// octant both forms compute the same numbers (fl is monotone: lo <= hi gives fma(lo, i, n) <= fma(hi, i, n) for i > 0 and
+// the reverse for i < 0, so min and max pick what the octant form names), hence the same votes; the other lanes are not
+// walking and their votes are masked.  Eight copies of the loop and the general one (oct = 8: signs differ among the
+// walking lanes), reached by a three-level branch on oct at entry.  The walk is bound by vector instructions (every
+// experiment that removed some paid; removing scalar ones or fetch latency did not: profiles/r03).
+//
 // Leaves are handed back to C++ (leaf_triangles): their primitive tests, the candidates' own boxes and the any-hit rule
 // are per-lane work whose rare paths (exact divisions, square roots) the compiler writes better than I would.
 // The record lives in FIXED scalar registers, s[64:71]: an inline-assembly operand that is a register tuple cannot be
@@ -756,72 +769,139 @@ __device__ __forceinline__ bool plane_rules_out(const TriRec &g, float ox, float
 #ifndef RTX_ASM_WALK
 #define RTX_ASM_WALK 1
 #endif
+#ifndef RTX_OCTANT_STEP
+#define RTX_OCTANT_STEP 1
+#endif
+// the octant of the walking lanes' directions (bit a: component a negative), 8 when they differ; ix, iy, iz = 1/d, regular
+__device__ __forceinline__ uint32_t walk_octant(const LaneRay &r, unsigned long long alive)
+{
+#if RTX_OCTANT_STEP
+    const unsigned long long mx = ballot(r.ix < 0.0f) & alive, my = ballot(r.iy < 0.0f) & alive, mz = ballot(r.iz < 0.0f) & alive;
+    const bool uniform = (mx == 0ull || mx == alive) && (my == 0ull || my == alive) && (mz == 0ull || mz == alive);
+    // (readfirstlane: the compiler otherwise forms this wave-uniform integer with vector selects and hands the assembly a vector register)
+    return __builtin_amdgcn_readfirstlane(uniform ? (mx != 0ull ? 1u : 0u) | (my != 0ull ? 2u : 0u) | (mz != 0ull ? 4u : 0u) : 8u);
+#else
+    return 8u;
+#endif
+}
 template <bool COUNT>
 __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__restrict__ nodes, uint32_t &off, uint32_t end,
-                                                unsigned long long alive, const LaneRay &r, uint32_t &link, uint32_t &info,
-                                                uint32_t &visits)
+                                                unsigned long long alive, const LaneRay &r, uint32_t oct, uint32_t &link,
+                                                uint32_t &info, uint32_t &visits)
 {
     float a, b, c, d, e, f, g;
     unsigned long long m;
     uint32_t nxt, skip;
     uint32_t o = off, w6, w7, n = visits;
     const float px = -r.nx, py = -r.ny, pz = -r.nz;   // o * (1/d): the ray keeps these; the step subtracts by operand modifier
-#define RTX_ADVANCE_BODY(COUNT_LINE)                                                                                      \
-        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                 \
-        "s_cbranch_scc0 .Lend%=\n"                                                                                        \
-        ".Lloop%=:\n\t"                                                                                                   \
-        "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"                                                                    \
-        COUNT_LINE                                                                                                        \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                        \
-        "s_add_u32 %[nxt], %[off], 32\n\t"                                                                                \
-        "v_fma_f32 %[a], s64, %[ix], -%[px]\n\t"   /* lo.x */                                                              \
-        "v_fma_f32 %[b], s66, %[ix], -%[px]\n\t"   /* hi.x */                                                              \
-        "v_fma_f32 %[c], s65, %[iy], -%[py]\n\t"   /* lo.y */                                                              \
-        "v_fma_f32 %[d], s67, %[iy], -%[py]\n\t"   /* hi.y */                                                              \
-        "v_fma_f32 %[e], s68, %[iz], -%[pz]\n\t"   /* lo.z */                                                              \
-        "v_fma_f32 %[f], s69, %[iz], -%[pz]\n\t"   /* hi.z */                                                              \
-        "v_min_f32 %[g], %[a], %[b]\n\t"                                                                                  \
-        "v_max_f32 %[a], %[a], %[b]\n\t"                                                                                  \
-        "v_min_f32 %[b], %[c], %[d]\n\t"                                                                                  \
-        "v_max_f32 %[c], %[c], %[d]\n\t"                                                                                  \
-        "v_min_f32 %[d], %[e], %[f]\n\t"                                                                                  \
-        "v_max_f32 %[e], %[e], %[f]\n\t"                                                                                  \
-        "v_max3_f32 %[g], %[g], %[b], %[d]\n\t"   /* entry */                                                             \
-        "v_min3_f32 %[a], %[a], %[c], %[e]\n\t"   /* exit */                                                              \
-        "v_cmp_ngt_f32 vcc, %[g], %[a]\n\t"       /* !(entry > exit): a NaN can only accept */                            \
-        "v_cmp_ngt_f32 %[m], 0, %[a]\n\t"         /* !(exit < 0) */                                                       \
-        "s_and_b64 vcc, vcc, %[m]\n\t"                                                                                    \
-        "s_and_b64 vcc, vcc, %[alive]\n\t"        /* SCC = some walking lane passes */                                    \
-        "s_cbranch_scc0 .Lnone%=\n\t"                                                                                     \
-        "s_cmp_lt_i32 s71, 0\n\t"                                                                                         \
-        "s_cbranch_scc1 .Lout%=\n\t"              /* a leaf to visit */                                                   \
-        "s_mov_b32 %[off], %[nxt]\n\t"            /* into the subtree: the next record (always inside the range) */       \
-        "s_branch .Lloop%=\n"                                                                                             \
-        ".Lnone%=:\n\t"                                                                                                   \
-        "s_lshl_b32 %[skip], s70, 5\n\t"                                                                                  \
-        "s_cmp_lt_i32 s71, 0\n\t"                                                                                         \
-        "s_cselect_b32 %[off], %[nxt], %[skip]\n\t" /* behind a leaf: the next record; else: behind the subtree */        \
-        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                 \
-        "s_cbranch_scc1 .Lloop%=\n"                                                                                       \
-        ".Lend%=:\n\t"                                                                                                    \
-        "s_mov_b32 s71, 0\n"                                                                                              \
+    // record words: s64 lo.x  s65 lo.y  s66 hi.x  s67 hi.y  s68 lo.z  s69 hi.z  s70 link  s71 info
+#define RTX_BOX_OCTANT(NX, FX, NY, FY, NZ, FZ)                                                                           \
+        "v_fma_f32 %[a], " NX ", %[ix], -%[px]\n\t"                                                                      \
+        "v_fma_f32 %[b], " FX ", %[ix], -%[px]\n\t"                                                                      \
+        "v_fma_f32 %[c], " NY ", %[iy], -%[py]\n\t"                                                                      \
+        "v_fma_f32 %[d], " FY ", %[iy], -%[py]\n\t"                                                                      \
+        "v_fma_f32 %[e], " NZ ", %[iz], -%[pz]\n\t"                                                                      \
+        "v_fma_f32 %[f], " FZ ", %[iz], -%[pz]\n\t"                                                                      \
+        "v_max_f32 %[e], 0, %[e]\n\t"                                                                                    \
+        "v_max3_f32 %[a], %[a], %[c], %[e]\n\t"   /* max(entry, 0) */                                                    \
+        "v_min3_f32 %[b], %[b], %[d], %[f]\n\t"   /* exit */                                                             \
+        "v_cmp_ngt_f32 vcc, %[a], %[b]\n\t"       /* !(max(entry, 0) > exit): a NaN can only accept */
+#define RTX_BOX_GENERAL                                                                                                  \
+        "v_fma_f32 %[a], s64, %[ix], -%[px]\n\t"                                                                         \
+        "v_fma_f32 %[b], s66, %[ix], -%[px]\n\t"                                                                         \
+        "v_fma_f32 %[c], s65, %[iy], -%[py]\n\t"                                                                         \
+        "v_fma_f32 %[d], s67, %[iy], -%[py]\n\t"                                                                         \
+        "v_fma_f32 %[e], s68, %[iz], -%[pz]\n\t"                                                                         \
+        "v_fma_f32 %[f], s69, %[iz], -%[pz]\n\t"                                                                         \
+        "v_min_f32 %[g], %[a], %[b]\n\t"                                                                                 \
+        "v_max_f32 %[a], %[a], %[b]\n\t"                                                                                 \
+        "v_min_f32 %[b], %[c], %[d]\n\t"                                                                                 \
+        "v_max_f32 %[c], %[c], %[d]\n\t"                                                                                 \
+        "v_min_f32 %[d], %[e], %[f]\n\t"                                                                                 \
+        "v_max_f32 %[e], %[e], %[f]\n\t"                                                                                 \
+        "v_max3_f32 %[g], %[g], %[b], %[d]\n\t"   /* entry */                                                            \
+        "v_min3_f32 %[a], %[a], %[c], %[e]\n\t"   /* exit */                                                             \
+        "v_cmp_ngt_f32 vcc, %[g], %[a]\n\t"       /* !(entry > exit): a NaN can only accept */                           \
+        "v_cmp_ngt_f32 %[m], 0, %[a]\n\t"         /* !(exit < 0) */                                                      \
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+    // one copy of the loop: K names its labels, BOX is its box test (leaves the passing lanes in vcc)
+#define RTX_ADVANCE_LOOP(K, COUNT_LINE, BOX)                                                                             \
+        ".Lloop" K "_%=:\n\t"                                                                                            \
+        "s_load_dwordx8 s[64:71], %[base], %[off]\n\t"                                                                   \
+        COUNT_LINE                                                                                                       \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
+        "s_add_u32 %[nxt], %[off], 32\n\t"                                                                               \
+        BOX                                                                                                              \
+        "s_and_b64 vcc, vcc, %[alive]\n\t"        /* SCC = some walking lane passes */                                   \
+        "s_cbranch_scc0 .Lnone" K "_%=\n\t"                                                                              \
+        "s_cmp_lt_i32 s71, 0\n\t"                                                                                        \
+        "s_cbranch_scc1 .Lout%=\n\t"              /* a leaf to visit */                                                  \
+        "s_mov_b32 %[off], %[nxt]\n\t"            /* into the subtree: the next record (always inside the range) */      \
+        "s_branch .Lloop" K "_%=\n"                                                                                       \
+        ".Lnone" K "_%=:\n\t"                                                                                            \
+        "s_lshl_b32 %[skip], s70, 5\n\t"                                                                                 \
+        "s_cmp_lt_i32 s71, 0\n\t"                                                                                        \
+        "s_cselect_b32 %[off], %[nxt], %[skip]\n\t" /* behind a leaf: the next record; else: behind the subtree */       \
+        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                \
+        "s_cbranch_scc1 .Lloop" K "_%=\n\t"                                                                              \
+        "s_branch .Lend%=\n"
+#define RTX_ADVANCE_BODY(COUNT_LINE)                                                                                     \
+        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                \
+        "s_cbranch_scc0 .Lend%=\n\t"                                                                                     \
+        "s_bitcmp1_b32 %[oct], 3\n\t"                                                                                    \
+        "s_cbranch_scc1 .Lloop8_%=\n\t"                                                                                  \
+        "s_bitcmp1_b32 %[oct], 2\n\t"                                                                                    \
+        "s_cbranch_scc1 .Lz%=\n\t"                                                                                       \
+        "s_bitcmp1_b32 %[oct], 1\n\t"                                                                                    \
+        "s_cbranch_scc1 .Ly0%=\n\t"                                                                                      \
+        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
+        "s_cbranch_scc1 .Lloop1_%=\n\t"                                                                                  \
+        "s_branch .Lloop0_%=\n"                                                                                          \
+        ".Ly0%=:\n\t"                                                                                                    \
+        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
+        "s_cbranch_scc1 .Lloop3_%=\n\t"                                                                                  \
+        "s_branch .Lloop2_%=\n"                                                                                          \
+        ".Lz%=:\n\t"                                                                                                     \
+        "s_bitcmp1_b32 %[oct], 1\n\t"                                                                                    \
+        "s_cbranch_scc1 .Ly1%=\n\t"                                                                                      \
+        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
+        "s_cbranch_scc1 .Lloop5_%=\n\t"                                                                                  \
+        "s_branch .Lloop4_%=\n"                                                                                          \
+        ".Ly1%=:\n\t"                                                                                                    \
+        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
+        "s_cbranch_scc1 .Lloop7_%=\n\t"                                                                                  \
+        "s_branch .Lloop6_%=\n"                                                                                          \
+        RTX_ADVANCE_LOOP("0", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s65", "s67", "s68", "s69"))                      \
+        RTX_ADVANCE_LOOP("1", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s65", "s67", "s68", "s69"))                      \
+        RTX_ADVANCE_LOOP("2", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s67", "s65", "s68", "s69"))                      \
+        RTX_ADVANCE_LOOP("3", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s67", "s65", "s68", "s69"))                      \
+        RTX_ADVANCE_LOOP("4", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s65", "s67", "s69", "s68"))                      \
+        RTX_ADVANCE_LOOP("5", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s65", "s67", "s69", "s68"))                      \
+        RTX_ADVANCE_LOOP("6", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s67", "s65", "s69", "s68"))                      \
+        RTX_ADVANCE_LOOP("7", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s67", "s65", "s69", "s68"))                      \
+        RTX_ADVANCE_LOOP("8", COUNT_LINE, RTX_BOX_GENERAL)                                                               \
+        ".Lend%=:\n\t"                                                                                                   \
+        "s_mov_b32 s71, 0\n"                                                                                             \
         ".Lout%=:"
     if (COUNT) {
         asm volatile(RTX_ADVANCE_BODY("s_add_u32 %[n], %[n], 1\n\t")
                      : [off] "+s"(o), [n] "+s"(n), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
                        [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
-                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz),
-                       [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
+                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),
+                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
                      : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69");
     } else {
         asm volatile(RTX_ADVANCE_BODY("")
                      : [off] "+s"(o), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
                        [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
-                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz),
-                       [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
+                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),
+                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
                      : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69");
     }
 #undef RTX_ADVANCE_BODY
+#undef RTX_ADVANCE_LOOP
+#undef RTX_BOX_GENERAL
+#undef RTX_BOX_OCTANT
     // The statement above returns scalar AND vector registers, so the compiler's value for "everything it returns" is a
     // divergent one, and a member of it that is first read in ANOTHER basic block gets a vector register whatever its own
     // constraint says (ROCm 7.2: the cross-block register of an aggregate takes the aggregate's divergence) — the offset
@@ -841,13 +921,17 @@ __device__ __forceinline__ unsigned long long walk_range_fast(const NodeRec RTX_
                                                               const TriRec RTX_CONSTANT *__restrict__ tris,
                                                               const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
                                                               LaneRay &r, unsigned long long alive,
-                                                              unsigned long long &n_active, WaveCounters &wc)
+                                                              unsigned long long &n_active, WaveCounters &wc,
+                                                              uint32_t oct_known = kNone)
 {
-    uint32_t off = i << 5;
-    const uint32_t end_off = end << 5;
+    // (readfirstlane: wave-uniform values, but where the compiler has merged them over branches it may hold them in vector
+    //  registers, which an "s" operand of the assembly cannot take)
+    uint32_t off = __builtin_amdgcn_readfirstlane(i << 5);
+    const uint32_t end_off = __builtin_amdgcn_readfirstlane(end << 5);
+    const uint32_t oct = oct_known != kNone ? oct_known : walk_octant(r, alive);     // (the lanes walking later are among these)
     for (;;) {
         uint32_t link, info, visits = 0u;
-        advance_to_leaf<COUNT>(nodes, off, end_off, alive, r, link, info, visits);
+        advance_to_leaf<COUNT>(nodes, off, end_off, alive, r, oct, link, info, visits);
         if (COUNT) { wc.box_tests += n_active * visits; wc.node_visits += visits; }
         if (info == 0u) break;
         if (SPHERES && (info & kSphereFlag))
@@ -872,10 +956,11 @@ __device__ __forceinline__ unsigned long long walk_range(const NodeRec RTX_CONST
                                                          const TriRec RTX_CONSTANT *__restrict__ tris,
                                                          const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
                                                          LaneRay &r, unsigned long long alive,
-                                                         unsigned long long &n_active, WaveCounters &wc)
+                                                         unsigned long long &n_active, WaveCounters &wc,
+                                                         uint32_t oct_known = kNone)
 {
 #if RTX_ASM_WALK && RTX_CULL_FMA && RTX_CULL_INFLATED && !RTX_CULL_PACKED
-    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc);
+    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc, oct_known);
 #endif
     while (i < end) {
 #if RTX_ASM_NODE_LOAD
@@ -1165,6 +1250,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
     // tile's shaft and miss most of the cut's roots, each of which used to cost one dependent scalar load.
     // (One loop over all ranges — refilling [i, end) inside walk_range's loop — was measured too: the loop's two-way
     //  exit costs five scalar instructions per record there, this nesting three, the whole-stream walk none.)
+    const uint32_t oct = USE_FAST ? walk_octant(r, alive) : kNone;   // once per chunk (advance_to_leaf); later walkers are among these lanes
     for (uint32_t k = 0; k < n_cut; ++k) {
         const uint32_t *e = cut + kCutWords * k;
         NodeRec root;   // NodeDev order: lo.x lo.y hi.x hi.y lo.z hi.z link info
@@ -1184,7 +1270,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
             if (COUNT) n_active = __popcll(alive);
         } else {
             const uint32_t begin = __builtin_amdgcn_readfirstlane(e[0]), end = __builtin_amdgcn_readfirstlane(e[1]);
-            alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc);
+            alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc, oct);
         }
         if (alive == 0ull) break;
     }
