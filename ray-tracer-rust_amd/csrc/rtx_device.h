@@ -90,7 +90,13 @@ struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc
 // 1: the kernels walk the four-child form of the tree (rtx_traverse.hpp: walk_wide) instead of the binary stream.  Same
 // bytes, measured slower on every configuration: kept as a build switch for A/B runs only.
 // (RTX_WIDE_WALK: default 0 in scene_prep.h, which also decides whether the four-child tree is built at all)
-constexpr uint32_t kMaxCut = RTX_MAX_CUT;    // <= 64: one wavefront holds the whole frontier of the cut's descent
+constexpr uint32_t kMaxCut = RTX_MAX_CUT;
+// Supported range of the A/B switch.  Above: a job stages its tile's cut with ONE word per work-item of its 512
+// (rtx_kernel.hip: cut_word), so kCutWords * kMaxCut <= 512 — the build of round 2's cut-size sweep that printed no bench
+// line (profiles/r02/h_ab_cut_size_with_roots_in_lds.log, "build 5" = 64 entries of the ten-word CutEntry = 640 words) left
+// entries 51..63 of every cut unstaged and walked whatever LDS held; the same sweep before the roots moved into the
+// entries (two words each, 128) had run.  Also <= 64: one wavefront holds the cut's frontier.  Below: an empty array.
+static_assert(kMaxCut >= 1u && kMaxCut <= 51u && kCutWords * kMaxCut <= 512u, "RTX_MAX_CUT: 1 .. 51 (one staged word per work-item of 512)");
 constexpr uint32_t kTileCutShift = 8u;       // TileDesc::flags
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);
 constexpr uint32_t kCostBuckets = 64u;

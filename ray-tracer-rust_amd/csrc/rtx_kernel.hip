@@ -175,9 +175,10 @@ __device__ __forceinline__ void shadow_result(const float *__restrict__ l_hit, f
 // x / denom for the divisor a whole launch shares (denom = NB_RAY * NB_LIGHT_SAMPLE, main.rs:211): the compiler's IEEE
 // division without its range scaling and fix-up — y = 1/denom once per kernel (reciprocal_ieee's steps), then q0 = x*y,
 // r0 = x - denom*q0, q1 = q0 + r0*y, r1 = x - denom*q1, q = q1 + r1*y with fused residuals, five instructions instead of
-// eleven.  The left-out steps do nothing for x = 0 and for 2^-60 <= x with 1 <= denom <= 2^30 (rtx_traverse.hpp:
+// eleven.  The left-out steps do nothing for x = 0 and for 2^-60 <= x <= 2^60 with 1 <= denom <= 2^30 (rtx_traverse.hpp:
 // divide3_ieee): the same instructions on the same values, the same bits — tools/div_denom_check.hip compares every
-// binary32 x in [2^-60, 4) for eighteen divisors.  A wavefront with a lane outside (tiny, negative, NaN) divides.
+// binary32 x in [2^-60, 2^60] for eighteen divisors.  A wavefront with a lane outside (tiny, huge, infinite — a caller's
+// colour may be anything —, negative, NaN) divides.
 struct DenomDiv { float d, y; bool usable; };
 __device__ __forceinline__ DenomDiv denom_div(float denom)
 {
@@ -190,7 +191,7 @@ __device__ __forceinline__ DenomDiv denom_div(float denom)
 }
 __device__ __forceinline__ float div_denom(float x, const DenomDiv &dd)
 {
-    if (!dd.usable || ballot(!(x == 0.0f || x >= 0x1p-60f)) != 0ull) return x / dd.d;
+    if (!dd.usable || ballot(!(x == 0.0f || (x >= 0x1p-60f && x <= 0x1p60f))) != 0ull) return x / dd.d;
     const float q0 = x * dd.y;
     const float r0 = __builtin_fmaf(-dd.d, q0, x);
     const float q1 = __builtin_fmaf(r0, dd.y, q0);
@@ -1190,7 +1191,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // loop takes over.  These tiles are bound by their vector instructions: 0.36 ms of a 0.41 ms
                     // ground-only frame, 81 % of big_bunny 4096x4096.
                     uint32_t c_first = wave * 64u;
-#if RTX_OPEN_GROUND_LOOP && !RTX_EXPERIMENT_NO_WALK && !RTX_EXPERIMENT_PAIR && !RTX_WIDE_WALK
+#if RTX_OPEN_GROUND_LOOP && !RTX_WIDE_WALK
                     if (!WHOLE && full_tile && grey_tile && n_cut == 0u && have_plane && S.n_global == 1u && denom_d.usable) {
 #if !RTX_FULL_TILE_GENERAL      // the registers are this loop's alone: loaded here, dead behind it
 #pragma unroll
@@ -1219,7 +1220,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             // a numerator outside their range is the general loop's — no loop-invariant flag is tested here:
                             // as lane masks in spilled scalar registers two of them cost four reloads per chunk)
                             const float x = my_hit[6] * lnd;
-                            if (ballot(!(x == 0.0f || x >= 0x1p-60f)) != 0ull) break;
+                            if (ballot(!(x == 0.0f || (x >= 0x1p-60f && x <= 0x1p60f))) != 0ull) break;
                             const float q0 = x * dy_;
                             const float q1 = __builtin_fmaf(__builtin_fmaf(-dd_, q0, x), dy_, q0);
                             l_res[__umul24(lane, res_stride) + sample] = __builtin_fmaf(__builtin_fmaf(-dd_, q1, x), dy_, q1);
@@ -1227,15 +1228,6 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     }
 #endif
                     for (uint32_t c0 = c_first; c0 < total; c0 += 64u * NW) {
-#if RTX_EXPERIMENT_PAIR         // counting experiment only (wrong pixels): what the union of a walk's records grows by when each
-                                // ray is joined by its partner one pixel (pixel-major) or one sample (sample-major) on: lanes
-                                // 0..31 keep their rays; 1: lanes 32..63 idle, 2: lanes 32..63 take the partners
-                        const uint32_t ray_no = c0 + (lane & 31u) + (lane >= 32u ? div : 0u);
-                        const bool valid = ray_no < total && (RTX_EXPERIMENT_PAIR == 2 || lane < 32u);
-                        const uint32_t quo = (uint32_t)(((float)ray_no + 0.5f) * inv_div);
-                        const uint32_t rem = ray_no - __umul24(quo, div);
-                        ShadowRay sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
-#else
                         ShadowRay sr;
                         if (RTX_FULL_TILE_GENERAL && full_tile) {   // chunk = light sample c0 / 64 of the tile's 64 pixels
                             sr = shadow_ray_from(my_hit, l_light, true, lane, c0 >> 6);
@@ -1245,7 +1237,6 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             const uint32_t rem = (c0 + lane) - __umul24(quo, div);
                             sr = shadow_ray_at(l_hit, l_light, valid, valid ? quo : 0u, valid ? rem : 0u, sample_major);
                         }
-#endif
                         const bool no_ground = have_plane &&
                             ((RTX_FULL_TILE_GENERAL && full_tile) ? ballot(!plane_rules_out(plane0, my_plane, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull
                                        : ballot(sr.ray.active && !plane_rules_out(plane0, sr.ray.ox, sr.ray.oy, sr.ray.oz, sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull);
@@ -1254,10 +1245,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         // directions (closest_hit: such a tile is re-rendered against the reference's tree).  Three of four
                         // chunks of a frame of the default scene are of this kind.
                         bool ok;
-#if RTX_EXPERIMENT_NO_WALK      // timing experiment only (wrong pixels): what a frame costs without any walk
-                        ok = true;
-                        (void)no_ground;
-#elif RTX_WIDE_WALK
+#if RTX_WIDE_WALK
                         ray_cull_constants(sr.ray);
                         ok = hit_wide<COUNT, FAST, SPHERES, true>(wide, S.n_wide, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
 #else
@@ -1285,11 +1273,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     ph_t[3] = wall_clock64();
 #endif
                     // phase 3: ordered accumulation, one work-item per pixel (wave 0)
-#if RTX_EXPERIMENT_NO_SUM       // timing experiment only (wrong pixels): what a frame costs without the ordered sums
-                    if (false) {
-#else
                     if (wave == 0) {
-#endif
                         if (threadIdx.x == 0 && b0 + batch >= S.nb_light) {          // last batch: the claimed position -> job id
                             if (!xcd_queues) {
                                 if (!claim_early) q_ahead = atomicAdd(&queue[kQueueNextTile], 1u);
@@ -1550,3 +1534,38 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 }
 
 }  // namespace rtx
+
+// What this library was built with: every compile-time switch of the kernel sources and its value, as text in the
+// binary.  tests/test_host_prep.py compares the string in the shipped librtx.so with the one a preprocessor run without
+// any -D produces, and checks that no switch of the sources is missing here: an A/B build cannot be mistaken for the
+// product.  (The timing instrumentation switches count as well: they cost time.)
+#ifndef RTX_EXPERIMENT_TIMELINE
+#define RTX_EXPERIMENT_TIMELINE 0
+#endif
+#ifndef RTX_EXPERIMENT_PHASES
+#define RTX_EXPERIMENT_PHASES 0
+#endif
+#ifndef RTX_EXPERIMENT_PROBE_PHASES
+#define RTX_EXPERIMENT_PROBE_PHASES 0
+#endif
+#ifndef RTX_ABLATION
+#define RTX_ABLATION 0
+#endif
+#define RTX_SW_STR2(x) #x
+#define RTX_SW_STR(x) RTX_SW_STR2(x)
+#define RTX_SW(x) " " #x "=" RTX_SW_STR(x)
+extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
+    RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
+    RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
+    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
+    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT)
+    RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
+    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
+    RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD)
+    RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
+    RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)
+    RTX_SW(RTX_TILE_BLOCKS) RTX_SW(RTX_TILE_PARTS_MAX) RTX_SW(RTX_TRIANGLE_EARLY_OUT)
+    RTX_SW(RTX_TRI_TOUCH_NEXT) RTX_SW(RTX_WALK_INTEGER_FLAGS) RTX_SW(RTX_WALK_SINGLE_EXIT)
+    RTX_SW(RTX_WAVES_PER_SIMD) RTX_SW(RTX_WIDE_WALK) RTX_SW(RTX_XCD_QUEUES)
+    RTX_SW(RTX_EXPERIMENT_TIMELINE) RTX_SW(RTX_EXPERIMENT_PHASES) RTX_SW(RTX_EXPERIMENT_PROBE_PHASES) RTX_SW(RTX_ABLATION);
+#undef RTX_SW

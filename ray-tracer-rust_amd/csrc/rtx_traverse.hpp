@@ -824,19 +824,6 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
         "v_cmp_ngt_f32 vcc, %[g], %[a]\n\t"       /* !(entry > exit): a NaN can only accept */                           \
         "v_cmp_ngt_f32 %[m], 0, %[a]\n\t"         /* !(exit < 0) */                                                      \
         "s_and_b64 vcc, vcc, %[m]\n\t"
-    // (sensitivity experiment, A/B builds only: what a record's step costs when it carries six more independent vector
-    //  instructions / six more scalar ones / 24 idle cycles — which of the three a walk is bound by)
-#if RTX_EXPERIMENT_PAD == 1
-#define RTX_STEP_PADDING "v_mov_b32 %[c], %[ix]\n\tv_mov_b32 %[d], %[iy]\n\tv_mov_b32 %[e], %[iz]\n\tv_mov_b32 %[f], %[px]\n\tv_mov_b32 %[c], %[py]\n\tv_mov_b32 %[d], %[pz]\n\t"
-#elif RTX_EXPERIMENT_PAD == 2
-#define RTX_STEP_PADDING "s_mov_b32 %[skip], 0\n\ts_mov_b32 %[skip], 1\n\ts_mov_b32 %[skip], 2\n\ts_mov_b32 %[skip], 3\n\ts_mov_b32 %[skip], 4\n\ts_mov_b32 %[skip], 5\n\t"
-#elif RTX_EXPERIMENT_PAD == 4   /* one more DEPENDENT scalar load of a word that is in the scalar cache by now, waited for: one hit's latency */
-#define RTX_STEP_PADDING "s_load_dword %[skip], %[base], %[off]\n\ts_waitcnt lgkmcnt(0)\n\t"
-#elif RTX_EXPERIMENT_PAD == 3
-#define RTX_STEP_PADDING "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
-#else
-#define RTX_STEP_PADDING ""
-#endif
     // one copy of the loop: K names its labels, BOX is its box test (leaves the passing lanes in vcc)
 #define RTX_ADVANCE_LOOP(K, COUNT_LINE, BOX)                                                                             \
         ".Lloop" K "_%=:\n\t"                                                                                            \
@@ -845,7 +832,6 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
         "s_add_u32 %[nxt], %[off], 32\n\t"                                                                               \
         BOX                                                                                                              \
-        RTX_STEP_PADDING                                                                                                 \
         "s_and_b64 vcc, vcc, %[alive]\n\t"        /* SCC = some walking lane passes */                                   \
         "s_cbranch_scc0 .Lnone" K "_%=\n\t"                                                                              \
         "s_cmp_lt_i32 s71, 0\n\t"                                                                                        \
@@ -914,7 +900,6 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
     }
 #undef RTX_ADVANCE_BODY
 #undef RTX_ADVANCE_LOOP
-#undef RTX_STEP_PADDING
 #undef RTX_BOX_GENERAL
 #undef RTX_BOX_OCTANT
     // The statement above returns scalar AND vector registers, so the compiler's value for "everything it returns" is a

@@ -270,6 +270,21 @@ def test_full_size_1080p_whole_frame_against_the_oracle(rtx, orc, samples_seeded
     assert_image_close(img3[800:802], ref, "bunny.obj 1080p")
 
 
+def test_configs1_bunny_1080p_whole_frame_against_the_oracle(rtx, orc, samples_seeded):
+    """BASELINE configs[1] at full size with the seeded table: EVERY byte of the 1920x1080 frame of bunny.obj against the
+    oracle's faithful BVH.  The mesh is sub-pixel under the hard-coded camera, so the frame is the ground
+    plane's soft-lit half — the open-ground path of shade_tiles_kernel on all of it — and costs the oracle ~15 s."""
+    W, H = 1920, 1080
+    with rtx.default_scene([model("bunny.obj")], W, H, samples_seeded) as s:
+        img, st = s.render_rows(stats=True)
+        assert np.array_equal(s.render_frame((0,), 8), img)
+    ref, ost = orc.default_scene(["bunny.obj"], W, H, samples_seeded).render_rows(mode=orc.MODE_BVH)
+    assert st["primary_hits"] == ost["primary_hits"] and st["redo_tiles"] == 0
+    assert st["rays"] == W * H + 100 * ost["primary_hits"]
+    assert ost["nonfinite_t"] == 0 and ost["assert_tmin_gt_tmax"] == 0
+    assert assert_image_close(img, ref, "bunny.obj 1080p seeded, whole frame") == 0
+
+
 def test_synthetic_1m_triangles_4096_square_full_size(rtx, orc, samples_seeded):
     """BASELINE configs[4] at ITS size: 1,000,000 random triangles + the ground (1,000,001 primitives), 4096x4096,
     through rtx_render_tiles_device (the entry point bench.py uses).

@@ -54,6 +54,33 @@ def test_product_library_has_one_pipeline_and_reads_no_environment(rtx):
     assert kernels < more and "trace_shade_kernel" in more
 
 
+def test_shipped_library_was_built_with_the_default_switches():
+    """The kernel sources carry compile-time switches for A/B builds (tools/ab_build.sh puts those builds under
+    gpurun_out/, never over the product).  librtx.so states what it was built with — rtx_build_switches_text, every
+    switch and its value — and that text must equal what the sources give with NO -D at all, and name every switch the
+    sources define: an experiment build in the product's place fails here."""
+    csrc = os.path.join(ROOT, "ray-tracer-rust_amd", "csrc")
+    blob = open(os.path.join(ROOT, "ray-tracer-rust_amd", "librtx.so"), "rb").read()
+    shipped = set(m.decode() for m in re.findall(rb"rtx-build-switches:[ -~]*", blob))
+    assert len(shipped) == 1, shipped
+    shipped = shipped.pop()
+    pre = subprocess.run(["/opt/rocm/bin/hipcc", "-E", "--cuda-host-only", "-std=c++17", "-I", csrc, os.path.join(csrc, "rtx_kernel.hip")],
+                         capture_output=True, text=True, check=True).stdout
+    decl = pre[pre.index("rtx_build_switches_text[]"):]
+    default = "".join(re.findall(r'"([^"]*)"', decl[:decl.index(";")]))
+    assert shipped == default, "librtx.so was not built with the default switches:\n%s\n%s" % (shipped, default)
+    named = set(re.findall(r" (RTX_[A-Z0-9_]+)=", shipped))
+    defined = set()
+    for f in ("rtx_device.h", "rtx_traverse.hpp", "rtx_kernel.hip", "scene_prep.h", "rtx_ablation_kernels.hpp", "rtx_traverse_ablation.hpp"):
+        src = open(os.path.join(csrc, f)).read()
+        defined |= set(re.findall(r"^#ifndef (RTX_[A-Z0-9_]+)$", src, re.M))
+        defined |= set(re.findall(r"^#\s*(?:if|elif)[^\n]*\b(RTX_EXPERIMENT_[A-Z0-9_]+)", src, re.M))
+    assert defined <= named, "switches missing from rtx_build_switches_text: %s" % sorted(defined - named)
+    assert " RTX_ABLATION=0" in shipped
+    abl = open(os.path.join(ROOT, "ray-tracer-rust_amd", "librtx_ablation.so"), "rb").read()
+    assert b" RTX_ABLATION=1" in abl
+
+
 def test_no_device_means_error_not_fallback(rtx, samples_half):
     if rtx.device_count() > 0:
         pytest.skip("a GPU is present")

@@ -2,7 +2,7 @@
 // div_denom — the sample's contribution (colour * |n.l|) / (NB_RAY * NB_LIGHT_SAMPLE), main.rs:211-215), computed as
 //   y = 1/d (v_rcp_f32 + one Newton step), q0 = x*y; r0 = fma(-d,q0,x); q1 = fma(r0,y,q0); r1 = fma(-d,q1,x); q = fma(r1,y,q1)
 // — the compiler's IEEE division without its range scaling and fix-up — against x / d for EVERY binary32 x in
-// [2^-60, 4) and a list of divisors in [1, 2^30].
+// [2^-60, 2^60] and a list of divisors in [1, 2^30] (the range div_denom admits; 2.0e9 inputs per divisor).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/div_denom_check.hip -o tools/div_denom_check
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -41,7 +41,7 @@ int main()
                               65535.0f, 1000000.0f, 16777215.0f, 1073741824.0f};
     unsigned long long *d_m;
     hipMalloc(&d_m, 8);
-    const uint32_t first = (127u - 60u) << 23, last = (127u + 2u) << 23;     // [2^-60, 4)
+    const uint32_t first = (127u - 60u) << 23, last = ((127u + 60u) << 23) + 1u;     // [2^-60, 2^60]
     unsigned long long total = 0, bad = 0;
     for (float d : divisors) {
         hipMemset(d_m, 0, 8);
