@@ -15,11 +15,14 @@ output stays in HBM (torch tensor).  torch is plumbing here: device memory, stre
 torch.distributed.  Every ray is traced by the HIP kernels behind the C ABI (include/rtx.h).
 
 One JSON line on stdout (rank 0).  Besides the contract fields:
-  roofline       dominant kernel (shade_tiles_kernel, the shading pass of a launch) against the HBM roof, as the
-                 contract asks, timed by the library's HIP events around that pass on the launch's stream
-                 (rtx_launch_timings); algorithmic bytes defined in DESIGN.md section 5.  The kernel is bound by
-                 instruction issue (vector and scalar), not by HBM — the whole scene is L2-resident — so
-                 "roofline_valu" (whole launch) is printed next to it.
+  roofline       the roof that BINDS the workload, as SURVEY 8(d) asks: FP32 VALU for the OBJ configurations (their
+                 records, 0.6 MB, live in L2 and the scalar cache), HBM for the synthetic 1M-triangle mesh (89 MB of
+                 records) — a copy of roofline_valu resp. roofline_hbm, which are both always printed.  roofline_hbm: the
+                 dominant kernel (shade_tiles_kernel, the shading pass of a launch) timed by the library's HIP events
+                 around that pass on the launch's stream (rtx_launch_timings), algorithmic bytes as in DESIGN.md section
+                 5; `traffic` = HBM bytes of that kernel from the PMC passes of an EARLIER profiled run (traffic_source
+                 says which), not of this run.
+  per_rank       every rank's own device times per launch (kernel, scheduling pass, shading pass): SURVEY 8(e).
   cpu_baseline   the CPU oracle in faithful-BVH mode (= the reference's src/tracer algorithm, "port") timed on this
                  box's host cores on a bounded sample of the same frame, with the reference's thread policy
                  (num_cpus - 1, src/main.rs:269) applied to the cores this job may use.
@@ -185,12 +188,18 @@ def reduce_counters(counters, world, via_host=False):
 
 
 def reduce_times(values, world, device):
-    """MAX over ranks of the timed region and of the per-launch device times."""
+    """MAX over ranks of the timed region and of the per-launch device times, and every rank's own values (SURVEY 8(e):
+    per-device kernel time, to expose imbalance): -> (max list, [per-rank list, ...])."""
     tt = torch.tensor(list(values), dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank = [t.cpu().tolist() for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    return tt.cpu().tolist()
+    else:
+        per_rank = [tt.cpu().tolist()]
+    return tt.cpu().tolist(), per_rank
 
 
 class Run:
@@ -307,7 +316,7 @@ def main():
     primary_rays = W * H * rtx.NB_RAY
     r_total = primary_rays + rtx.NB_LIGHT_SAMPLE * primary_hits
 
-    elapsed, kernel_s, sched_s, shade_s = run.timed(args.steps, args.warmup, via_host)
+    (elapsed, kernel_s, sched_s, shade_s), per_rank_times = run.timed(args.steps, args.warmup, via_host)
     ms_per_step = elapsed / args.steps * 1e3
     gpu_frame = run.frame() if world == 1 else None         # what the last timed step left in HBM
 
@@ -329,12 +338,14 @@ def main():
         run4 = Run(rtx, wl4, samples, rank, world, local_rank, dev, args.tile_rows)
         c4 = run4.counted(via_host)
         steps4 = max(3, args.steps // 2)
-        e4, k4, s4, h4 = run4.timed(steps4, min(args.warmup, 2), via_host)
+        (e4, k4, s4, h4), per_rank4 = run4.timed(steps4, min(args.warmup, 2), via_host)
         r4 = wl4["width"] * wl4["height"] * rtx.NB_RAY + rtx.NB_LIGHT_SAMPLE * c4[0]
         ms4 = e4 / steps4 * 1e3
         scaling = {"workload": wl4["desc"], "n_gpus": world, "steps": steps4, "ms_per_step": round(ms4, 4),
                    "value": round(r4 / (ms4 / 1e3) / 1e6, 3), "unit": "Mrays/s", "rays_per_frame": r4,
-                   "schedule_ms": round(s4 * 1e3, 4), "shade_ms": round(h4 * 1e3, 4)}
+                   "schedule_ms": round(s4 * 1e3, 4), "shade_ms": round(h4 * 1e3, 4),
+                   "per_rank": [{"rank": i, "kernel_ms": round(t[1] * 1e3, 4), "schedule_ms": round(t[2] * 1e3, 4),
+                                 "shade_ms": round(t[3] * 1e3, 4)} for i, t in enumerate(per_rank4)]}
         run4.scene.close()
 
     if rank == 0:
@@ -350,13 +361,17 @@ def main():
         ach_tf = flops / kernel_s / 1e12
         # SURVEY §8(d) brute-force-equivalent HBM-level bytes (G = 256 rays share a staged record)
         b_alg_brute = (-(-r_total // 256)) * info["n_tris"] * 36 + 11 * W * H
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                tr = json.load(f).get(args.workload, {})
+                tj = json.load(f)
+                tr = tj.get(args.workload, {})
                 # of the dominant kernel when the profile separates the kernels of a launch, else of the launch
                 traffic = tr.get("hbm_bytes_shade_kernel_n%d" % world) or tr.get("hbm_bytes_per_launch_n%d" % world)
+                if traffic is not None:
+                    traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of this workload (%s), not of this run" % (
+                        tr.get("profiled") or tj.get("profiled") or "profiles/traffic.json")
         pmc = None      # SQ counters of an earlier profiled run of the same workload (profiles/pmc_summary.json)
         ppath = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(ppath) and world == 1:
@@ -377,24 +392,28 @@ def main():
             "frame_ms": round(ms_per_step, 4),
             "rays_per_frame": r_total, "primary_hits": primary_hits,
             "primary_mrays_per_s": round(primary_rays / (ms_per_step / 1e3) / 1e6, 3),
-            "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "shade_tiles_kernel", "kernel_ms": round(shade_s * 1e3, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "launch": {"passes": "probe_kernel + order_tiles_kernel (scheduling), shade_tiles_kernel + "
-                                              "reference_tiles_kernel (shading)",
-                                    "schedule_ms": round(sched_s * 1e3, 4), "shade_ms": round(shade_s * 1e3, 4),
-                                    "launch_ms": round(kernel_s * 1e3, 4),
-                                    "survey_8d_bytes": int(launch_alg_bytes),
-                                    "survey_8d_gbs": round(launch_alg_bytes / kernel_s / 1e9, 3)},
-                         "note": "scene records %.2f MB (L2-resident when < 4 MB): the kernel is bound by instruction issue "
-                                 "and scalar-load latency, not HBM, see roofline_valu; survey_b_alg_* = SURVEY 8(d) "
-                                 "brute-force-equivalent bytes" % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),
-                         "redo_tiles": c[5],
-                         "survey_b_alg_bytes": int(b_alg_brute),
-                         "survey_b_alg_frac": round(b_alg_brute / world / kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline_valu": {"bound": "fp32-valu", "achieved": round(ach_tf, 3), "peak": VALU_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5),
+            "roofline": None,        # the roof that binds this workload: filled in below
+            "roofline_hbm": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                             "kernel": "shade_tiles_kernel", "kernel_ms": round(shade_s * 1e3, 4),
+                             "algorithmic_bytes_per_launch": int(alg_bytes),
+                             "launch": {"passes": "probe_kernel + order_tiles_kernel (scheduling), shade_tiles_kernel + "
+                                                  "reference_tiles_kernel (shading)",
+                                        "schedule_ms": round(sched_s * 1e3, 4), "shade_ms": round(shade_s * 1e3, 4),
+                                        "launch_ms": round(kernel_s * 1e3, 4),
+                                        "survey_8d_bytes": int(launch_alg_bytes),
+                                        "survey_8d_gbs": round(launch_alg_bytes / kernel_s / 1e9, 3)},
+                             "note": "scene records %.2f MB (L2-resident when < 4 MB); survey_b_alg_* = SURVEY 8(d) "
+                                     "brute-force-equivalent bytes" % ((info["node_bytes"] + info["tri_bytes"]) / 1e6),
+                             "redo_tiles": c[5],
+                             "survey_b_alg_bytes": int(b_alg_brute),
+                             "survey_b_alg_frac": round(b_alg_brute / world / kernel_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline_valu": {"bound": "valu", "achieved": round(ach_tf, 3), "peak": VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(ach_tf / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+                              "traffic_source": traffic_source,
+                              "kernel": "the launch (probe_kernel + shade_tiles_kernel: the counters do not separate their tests)",
+                              "kernel_ms": round(kernel_s * 1e3, 4),
+                              "algorithmic_flop_per_launch": int(flops),
                               # MI355X_MICROARCH.md: SIMD-32, a wave64 v_fma_f32 issues in 2 cycles; 157.3 TFLOP/s is reached
                               # with plain FMAs.  Pixel arithmetic here may not fuse (bit parity with the reference), so
                               # one flop per lane-slot: 78.6 Tflop/s is the ceiling of this instruction mix
@@ -403,8 +422,16 @@ def main():
                               "pmc": pmc,
                               "box_tests": box_tests, "tri_tests": tri_tests,
                               "wave_node_visits": node_visits, "wave_tri_visits": tri_visits},
+            "per_rank": [{"rank": i, "kernel_ms": round(t[1] * 1e3, 4), "schedule_ms": round(t[2] * 1e3, 4),
+                          "shade_ms": round(t[3] * 1e3, 4)} for i, t in enumerate(per_rank_times)],
             "host": host,
         }
+        # `roofline` := whichever roof binds — FP32 VALU for the OBJ configurations (their records are
+        # L2-resident: 0.6 MB), HBM for the synthetic 1M-triangle mesh (89 MB of records) —, the other always beside it
+        binding = "roofline_hbm" if wl.get("synthetic") else "roofline_valu"
+        line["roofline"] = dict(line[binding], other="roofline_valu" if binding == "roofline_hbm" else "roofline_hbm")
+        # (the ab tools read the two passes' times from the line's roofline block whichever roof it is)
+        line["roofline"]["launch"] = line["roofline_hbm"]["launch"]
         if incl_d2h:
             line.update(incl_d2h)
         if scaling:

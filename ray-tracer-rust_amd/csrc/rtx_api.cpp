@@ -216,6 +216,10 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     std::memcpy(S.cv, p.cam_v, 12);
     std::memcpy(S.cw, p.cam_w, 12);
     S.distance = p.distance;
+    S.cut_max_nodes = rtx::kCutMaxNodes;
+#if RTX_ABLATION   // librtx_ablation.so only: one scene with and without per-tile cuts (tests/test_gpu_pipeline.py)
+    if (const char *e = std::getenv("RTX_CUT_MAX_NODES")) S.cut_max_nodes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+#endif
     return S;
 }
 

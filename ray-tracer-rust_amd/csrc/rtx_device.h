@@ -36,7 +36,11 @@ struct DeviceScene {
     float eye[3], cu[3], cv[3], cw[3];
     float distance;
     float shaft_delta;             // margin of the tile shaft test in position units (PreparedScene::shaft_delta)
+    uint32_t cut_max_nodes;        // scenes of more stream records than this do not cut per tile: every chunk walks the whole
+                                   // stream.  kCutMaxNodes in librtx.so; librtx_ablation.so reads RTX_CUT_MAX_NODES (0 = never
+                                   // cut) so that a test can render ONE scene both ways and compare the bytes
 };
+constexpr uint32_t kCutMaxNodes = 1u << 16;
 
 // Which rows a launch renders: local row ly (0 <= ly < local_rows) is row
 //   first_row + (ly / tile_rows) * tile_stride_rows + ly % tile_rows

@@ -382,8 +382,6 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
 // in units of one fetched record: the weight of a tile whose cut is empty
 constexpr uint32_t kChunkFixedCost = 8u;
 
-// scenes of more stream records than this do not cut per tile (probe_kernel)
-constexpr uint32_t kCutMaxNodes = 1u << 16;
 
 // independent wavefronts (tiles) per workgroup of probe_kernel: 1, 4 and 8 measured the same (m_ab_probewaves.log)
 // 1: probe_kernel's primary walk on the four-child form of the tree (measured: the scheduling pass of one share of an
@@ -729,7 +727,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 #else
         // the tree proper: behind the root and the global triangles' leaf when there are any (scene_prep.cpp)
         const uint32_t root = S.n_global != 0u ? 2u : 0u;
-        if (root < S.n_nodes && S.n_nodes <= kCutMaxNodes) {
+        if (root < S.n_nodes && S.n_nodes <= S.cut_max_nodes) {
             n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut, l_front, lane, weight);
         } else if (root < S.n_nodes) {
             // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
@@ -1409,7 +1407,7 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
 #if RTX_WIDE_WALK
     const bool whole = false;
 #else
-    const bool whole = S.n_nodes > kCutMaxNodes;
+    const bool whole = S.n_nodes > S.cut_max_nodes;
 #endif
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);

@@ -1,6 +1,7 @@
 """GPU tests of the launch structure (probe_kernel -> count/order -> shade_tiles_kernel -> reference_tiles_kernel):
 the corners where the passes hand work to each other.  Results are still checked against the oracle."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -9,6 +10,7 @@ from test_host_spheres import mixed_scene
 
 pytestmark = pytest.mark.gpu
 F = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -203,3 +205,78 @@ def test_plane_shortcut_of_global_triangles(rtx, orc, samples_seeded, seed):
         img, st = s.render_rows(stats=True)
     assert st["primary_hits"] == ost["primary_hits"] > 0.5 * W * H
     assert np.array_equal(img, ref)
+
+
+_CUT_VS_WHOLE_CHILD = r"""
+import importlib, sys, hashlib, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+rtx = importlib.import_module('ray-tracer-rust_amd')
+F = np.float32
+T = rtx.gen_samples()[:8192]
+
+def soup(seed, n, centre, extent, size):
+    g = np.random.default_rng(seed)
+    c = g.uniform(-extent, extent, (n, 1, 3)) + np.asarray(centre, F)
+    t = (c + g.uniform(-size, size, (n, 3, 3))).astype(F).reshape(n, 9)
+    return t, g.uniform(0.2, 1.0, (n, 3)).astype(F)
+
+out = {}
+# 1. the light INSIDE the mesh: the light's box overlaps every tile's hit box, shafts run in every direction
+t, c = soup(1, 3000, (0, 0, 0), 40, 2.5)
+out['light inside'] = dict(tris=t, rgb=c, eye=(0, 10, 150), look_at=(0, 0, 0), distance=90.0,
+                           light_tri=np.array([-3, 1, -3, 3, 1, -3, 0, -2, 3], F), nb_light_sample=24)
+# 2. coordinates around one million: the margins of the shaft test are relative to the scene's magnitude
+t, c = soup(2, 2500, (1.0e6, 2.0e6, -1.5e6), 60, 4.0)
+floor = np.array([[1.0e6 - 500, 2.0e6 - 70, -1.5e6 + 500, 1.0e6 + 500, 2.0e6 - 70, -1.5e6 + 500, 1.0e6, 2.0e6 - 70, -1.5e6 - 800]], F)
+out['coordinates of a million'] = dict(tris=np.concatenate([t, floor]), rgb=np.concatenate([c, np.array([[0.5, 0.5, 0.5]], F)]),
+                                        eye=(1.0e6, 2.0e6 + 30, -1.5e6 + 260), look_at=(1.0e6, 2.0e6 - 20, -1.5e6), distance=100.0,
+                                        light_tri=np.array([1.0e6 - 15, 2.0e6 + 200, -1.5e6 - 10, 1.0e6 + 15, 2.0e6 + 200, -1.5e6 - 10, 1.0e6, 2.0e6 + 200, -1.5e6 + 12], F),
+                                        nb_light_sample=20)
+# 3. spheres among the triangles, and two primary rays per pixel
+t, c = soup(3, 1500, (0, 30, 0), 50, 3.0)
+g = np.random.default_rng(33)
+sph = np.concatenate([g.uniform(-50, 50, (200, 3)) + np.array([0, 30, 0]), g.uniform(0.5, 4.0, (200, 1))], axis=1).astype(F)
+floor = np.array([[-400, -25, 300, 400, -25, 300, 0, -25, -600]], F)
+out['spheres, two primary rays'] = dict(tris=np.concatenate([t, floor]), rgb=np.concatenate([c, np.array([[0.5, 0.5, 0.5]], F)]),
+                                         spheres=sph, sphere_rgb=g.uniform(0.2, 1.0, (200, 3)).astype(F),
+                                         eye=(0, 60, 220), look_at=(0, 20, 0), distance=110.0, nb_ray=2, nb_light_sample=16)
+res = {}
+for name, kw in out.items():
+    tris, rgb = kw.pop('tris'), kw.pop('rgb')
+    with rtx.Scene(160, 120, tris, rgb, T, **kw) as s:
+        info = s.info()
+        img, st = s.render_rows(stats=True)
+    res[name] = dict(sha=hashlib.sha1(img.tobytes()).hexdigest(), hits=int(st['primary_hits']), rays=int(st['rays']),
+                     lit=int((img.max(axis=2) > 0).sum()), nodes=int(info['n_nodes']), node_visits=int(st['wave_node_visits']))
+print('RESULT', json.dumps(res))
+"""
+
+
+def test_cut_and_whole_stream_walks_give_the_same_bytes():
+    """The per-tile shaft cut decides which subtrees a tile's shadow rays may see: a cut that is not
+    a superset would show as missing shadows.  The same scenes are rendered by librtx_ablation.so twice, each in a child
+    process — with the cuts, and with RTX_CUT_MAX_NODES=0, which makes every chunk walk the whole stream — and must give
+    the same bytes: the light inside the mesh (its box overlaps the tiles' hit boxes), coordinates around 10^6 (the
+    margins are relative), spheres with two primary rays per pixel."""
+    import json
+    import subprocess
+    import sys
+    code = _CUT_VS_WHOLE_CHILD % dict(root=ROOT)
+    results = []
+    for cut_max in (None, "0"):
+        env = dict(os.environ, RTX_PY_ABLATION="1")
+        env.pop("RTX_CUT_MAX_NODES", None)
+        if cut_max is not None:
+            env["RTX_CUT_MAX_NODES"] = cut_max
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, out.stderr[-1200:]
+        results.append(json.loads(line[0][7:]))
+    cut, whole = results
+    assert set(cut) == set(whole) and len(cut) == 3
+    for name in cut:
+        a, b = cut[name], whole[name]
+        assert a["hits"] == b["hits"] > 0 and a["rays"] == b["rays"] and a["lit"] > 0, (name, a, b)
+        assert a["sha"] == b["sha"], (name, a, b)
+        assert a["node_visits"] != b["node_visits"], "the two renders of %r walked the same records: one form ran twice" % name

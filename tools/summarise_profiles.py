@@ -14,6 +14,7 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 KERNELS = {"probe_kernel<false": "probe", "order_tiles_kernel": "order", "count_classes_kernel": "count", "shade_tiles_kernel<false": "shade",
@@ -92,7 +93,14 @@ def main():
             if c.get("SQ_INSTS_SALU") is not None:
                 e["salu_per_cu_per_cycle_at_2p4_ghz"] = round((c["SQ_INSTS_SALU"] + (c.get("SQ_INSTS_SMEM") or 0.0)) /
                                                               (ms * 1e-3 * 2.4e9 * N_CU), 4)
-            if c.get("GRBM_GUI_ACTIVE"):
+            if ms < 0.05:
+                # a dispatch of a few microseconds: its wall time is mostly launch overhead and GRBM_GUI_ACTIVE / 8 over it
+                # gives "clocks" of 5-7 GHz (MI355X_MICROARCH.md: the quotient reads high below ~0.3 ms); no clock, no
+                # busy figures for such a kernel — the raw counts above are what there is
+                e["note"] = "dispatch under 50 us: no derived clock or busy figures"
+                for key in ("valu_busy_at_2p4_ghz", "salu_per_cu_per_cycle_at_2p4_ghz"):
+                    e.pop(key, None)
+            elif c.get("GRBM_GUI_ACTIVE"):
                 # GRBM_GUI_ACTIVE / 8 = shader-clock cycles of the dispatch (the GRBM pass ran separately)
                 cycles = c["GRBM_GUI_ACTIVE"] / N_XCD
                 e["gpu_cycles"] = cycles
@@ -133,7 +141,10 @@ def main():
                     "write_size_kib_raw": {k: round(v, 1) for k, v in write.items()},
                     "hbm_bytes_per_launch_n1": int((2.0 * f_kib + w_kib) * 1024),
                     "hbm_bytes_shade_kernel_n1": int((2.0 * fetch.get("shade", 0.0) + write.get("shade", 0.0)) * 1024),
-                    "source": "%s/%s_pmc_%s_{fetch_size,write_size}.csv" % (os.path.relpath(dst, root), tag, wl)}
+                    "source": "%s/%s_pmc_%s_{fetch_size,write_size}.csv" % (os.path.relpath(dst, root), tag, wl),
+                    "profiled": "commit %s, profiles/%s" % (
+                        subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?",
+                        os.path.relpath(dst, os.path.join(root, "profiles")))}
         json.dump(allt, open(traffic_path, "w"), indent=1)
     print(json.dumps({"pmc": summary, "traffic": allt.get(wl)}, indent=1))
 
