@@ -39,6 +39,8 @@ struct DeviceScene {
     uint32_t cut_max_nodes;        // scenes of more stream records than this do not cut per tile: every chunk walks the whole
                                    // stream.  kCutMaxNodes in librtx.so; librtx_ablation.so reads RTX_CUT_MAX_NODES (0 = never
                                    // cut) so that a test can render ONE scene both ways and compare the bytes
+    uint32_t n_prims;              // primitive records (triangles + spheres)
+    uint32_t j1_mode;              // librtx_ablation.so only (RTX_J1, rtx_j1_ablation.hpp): 0 = the shipped pipeline; librtx.so: 0
 };
 constexpr uint32_t kCutMaxNodes = 1u << 16;
 

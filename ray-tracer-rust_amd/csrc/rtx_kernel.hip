@@ -489,6 +489,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+#if RTX_ABLATION
+#include "rtx_j1_ablation.hpp"
+#endif
+
 // Breadth-first descent of the wide tree with the shaft test, one frontier node per work-item; the frontier of a level
 // lives in registers (lane l holds its l-th node), the next one is gathered through 64 words of LDS.  A frontier
 // node's four child boxes are tested against the shaft.  A node with a LEAF child that meets the shaft becomes an
@@ -629,6 +633,9 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
     // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no barrier; LDS only inside shaft_cut)
     __shared__ uint32_t l_front_all[RTX_PROBE_WAVES][128];   // the cut's next frontier: node, subtree size
+#if RTX_ABLATION
+    __shared__ __align__(16) uint32_t l_j1_block[RTX_PROBE_WAVES][kJ1BlockWords];   // RTX_J1=2: a block of 64 primitive records
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *const l_front = l_front_all[wave_in_group];
@@ -660,6 +667,10 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     const bool ok = hit_wide<COUNT, FAST, SPHERES, false>((const WideNode RTX_CONSTANT *)S.wide, S.n_wide, tris, S.shade, nullptr, 0u, pr, wc,
                                                           S.n_global, false);                                  // main.rs:187
     (void)nodes;
+#elif RTX_ABLATION
+    const bool ok = (S.j1_mode == 2u || S.j1_mode == 3u)
+        ? j1_closest_hit_blocks<COUNT>(S.j1_mode, S.tris, S.shade, S.n_prims, pr, wc, lane, l_j1_block[wave_in_group])
+        : closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);               // main.rs:187
 #else
     const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
 #endif
@@ -991,6 +1002,10 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     uint32_t *const l_cut = l_ctl + 4u;                                                // the tile's cut: CutEntry records
     float *const l_thr = reinterpret_cast<float *>(l_cut + kCutWords * kMaxCut);        // the 256 gamma thresholds (eight dependent
     for (uint32_t k = threadIdx.x; k < 256u; k += 64u * NW) l_thr[k] = S.gamma_thr[k];   // reads per channel per pixel: LDS, not L1)
+#if RTX_ABLATION
+    uint32_t *const l_j1_win = reinterpret_cast<uint32_t *>(l_thr + 256u);             // RTX_J1=1 only (launch_probe sizes LDS for it)
+    if (S.j1_mode == 1u && threadIdx.x < 2u) l_j1_win[threadIdx.x] = 0u;               // "no window" until a job stages one
+#endif
 
 #if RTX_WIDE_WALK
     const WideNode RTX_CONSTANT *wide = (const WideNode RTX_CONSTANT *)S.wide;
@@ -1111,6 +1126,12 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                 for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = tile_hits[h0 * kHitStride + k];
             }
             if (threadIdx.x < kCutWords * n_cut) l_cut[threadIdx.x] = cut_word;
+#if RTX_ABLATION
+            if (!WHOLE && S.j1_mode == 1u) {      // the stream window of this tile's cut -> LDS (rtx_j1_ablation.hpp)
+                __syncthreads();
+                j1_stage_window(S.nodes, l_cut, n_cut, l_j1_win, 64u * NW);
+            }
+#endif
             if (wave == 0) {
                 const size_t pix = (size_t)tile_id * 64u + lane;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;                               // main.rs:182
@@ -1252,8 +1273,17 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             ok = sr.not_hard || ballot(sr.ray.active && direction_is_hard(sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull;
                         } else {
                             ray_cull_constants(sr.ray);                              // main.rs:204
+#if RTX_ABLATION
+                            if (whole_tree && S.j1_mode == 1u)
+                                ok = j1_any_hit_whole_vec<COUNT, SPHERES>(S.nodes, nodes, tris, S.shade, S.n_nodes, l_j1_win, sr.ray, wc, S.n_global, no_ground);
+                            else
+#endif
                             if (whole_tree)
                                 ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);
+#if RTX_ABLATION
+                            else if (S.j1_mode == 1u)
+                                ok = j1_any_hit_cut_vec<COUNT, SPHERES>(S.nodes, nodes, tris, S.shade, l_cut, n_cut, l_j1_win, sr.ray, wc, S.n_global, no_ground);
+#endif
                             else
                                 ok = any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);
                         }
@@ -1410,7 +1440,11 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     const bool whole = S.n_nodes > S.cut_max_nodes;
 #endif
     const uint32_t batch = S.nb_light < kMaxLightBatch ? (S.nb_light ? S.nb_light : 1u) : kMaxLightBatch;
+#if RTX_ABLATION
+    const size_t lds_bytes = (static_cast<size_t>(lds_floats(batch)) + (S.j1_mode == 1u ? kJ1WindowWords : 0u)) * sizeof(float);
+#else
     const size_t lds_bytes = static_cast<size_t>(lds_floats(batch)) * sizeof(float);
+#endif
     const uint32_t tiles_x = (S.width + 7u) / 8u, tiles_y = (ts.local_rows + 7u) / 8u;
     const uint32_t n_tiles = numbered_tiles(tiles_x, tiles_y);
     // persistent grid = what the device keeps resident of the form that is launched (the two forms differ in registers)

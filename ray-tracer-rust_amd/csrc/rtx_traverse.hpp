@@ -564,14 +564,39 @@ __device__ __forceinline__ bool own_box_passes(float lox, float loy, float loz, 
     return slab_exact(lox, loy, loz, hix, hiy, hiz, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
 }
 
-template <bool COUNT, bool ANYHIT = false, bool FAST_OK = false>
+#if RTX_ABLATION
+// librtx_ablation.so, RTX_J1=1 (rtx_j1_ablation.hpp): the same 64 bytes through the VECTOR memory path — four
+// global_load_dwordx4 of a wave-uniform address — so that the triangle test runs on vector-register operands
+__device__ __forceinline__ TriRec load_tri_vec(const TriRec RTX_CONSTANT *base, uint32_t index)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 a, b, c, d;
+    const uint32_t voff = index << 6;
+    asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:32\n\tglobal_load_dwordx4 %3, %4, %5 offset:48\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(voff), "s"(base) : "memory");
+    TriRec t;
+    t.v0[0] = __uint_as_float(a.x); t.v0[1] = __uint_as_float(a.y); t.v0[2] = __uint_as_float(a.z);
+    t.e1[0] = __uint_as_float(a.w); t.e1[1] = __uint_as_float(b.x); t.e1[2] = __uint_as_float(b.y);
+    t.e2[0] = __uint_as_float(b.z); t.e2[1] = __uint_as_float(b.w); t.e2[2] = __uint_as_float(c.x);
+    t.bmin[0] = __uint_as_float(c.y); t.bmin[1] = __uint_as_float(c.z); t.bmin[2] = __uint_as_float(c.w);
+    t.bmax[0] = __uint_as_float(d.x); t.bmax[1] = __uint_as_float(d.y); t.bmax[2] = __uint_as_float(d.z);
+    t.idx = __builtin_amdgcn_readfirstlane(d.w);
+    return t;
+}
+#endif
+
+template <bool COUNT, bool ANYHIT = false, bool FAST_OK = false, bool VEC = false>
 __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
                                                const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
                                                LaneRay &r, unsigned long long alive, unsigned long long n_active,
                                                WaveCounters &wc)
 {
     for (uint32_t k = 0; k < count; ++k) {
-#if RTX_ASM_TRI_LOAD
+#if RTX_ABLATION && RTX_ASM_TRI_LOAD
+        const TriRec rec = VEC ? load_tri_vec(tris, first + k) : load_tri_at(tris, first + k);
+        const TriRec *tr = &rec;
+#elif RTX_ASM_TRI_LOAD
         const TriRec rec = load_tri_at(tris, first + k);
         const TriRec *tr = &rec;
 #else

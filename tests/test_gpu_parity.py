@@ -438,3 +438,32 @@ def test_every_kernel_variant_gives_the_same_bytes(samples_seeded):
         assert line, (variant, out.stderr[-800:])
         _, sha, hits, rays = line[0].split()
         assert sha == want and int(hits) == case["primary_hits"] and int(rays) == case["r_total"], (variant, line[0])
+
+
+def test_north_star_variants_give_the_same_bytes(samples_seeded):
+    """BASELINE.json's north_star names a design — LDS-staged triangle blocks, wavefront-level min reductions for the
+    closest hit, records served from LDS — that the shipped pipeline replaced by a wave-uniform walk on scalar operands.
+    librtx_ablation.so carries it as three measurable modes (RTX_J1=1: the shading pass's records as vector operands out of
+    an LDS window / vector loads; 2: primary rays against LDS-staged blocks of 64 primitives, ray per lane; 3: triangle
+    per lane with a DPP min-reduction per ray; csrc/rtx_j1_ablation.hpp).  Each must reproduce the golden image; what
+    they cost is in DESIGN.md section 4 (profiles/r03/j1_*)."""
+    import hashlib
+    import subprocess
+    import sys
+    ref, case = golden("c1b_bigbunny_256_seed")
+    code = (
+        "import importlib, sys, hashlib; sys.path.insert(0, %r)\n"
+        "rtx = importlib.import_module('ray-tracer-rust_amd')\n"
+        "s = rtx.default_scene([%r], 256, 256, rtx.gen_samples())\n"
+        "img, st = s.render_rows(stats=True)\n"
+        "print('RESULT', hashlib.sha1(img.tobytes()).hexdigest(), st['primary_hits'], st['rays'])\n"
+    ) % (ROOT, model("big_bunny.obj"))
+    want = hashlib.sha1(np.ascontiguousarray(ref).tobytes()).hexdigest()
+    for mode in (1, 2, 3):
+        env = dict(os.environ, RTX_J1=str(mode), RTX_PY_ABLATION="1")
+        env.pop("RTX_VARIANT", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, (mode, out.stderr[-800:])
+        _, sha, hits, rays = line[0].split()
+        assert sha == want and int(hits) == case["primary_hits"] and int(rays) == case["r_total"], (mode, line[0])
