@@ -36,7 +36,7 @@ thread_local int g_last_hip_error = 0;
 struct DeviceState {
     std::mutex mu;
     bool uploaded = false;
-    void *nodes = nullptr, *nodes16 = nullptr, *wide = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr, *light_boxes = nullptr;
+    void *nodes = nullptr, *wide = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr, *light_boxes = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_out = nullptr;
@@ -132,7 +132,6 @@ int upload_all(RtxScene *scene, DeviceState &st)
     int rc;
     const float inflate = RTX_CULL_INFLATED ? p.cull_delta : 0.0f;
     if ((rc = upload_vec(&st.nodes, rtx::nodes_in_device_order(p.nodes, inflate), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
-    if (!p.nodes16.empty() && (rc = upload_vec(&st.nodes16, p.nodes16, sizeof(rtx::Node16))) != RTX_OK) return rc;
     if (!p.wide.empty()) {   // A/B builds only (scene_prep.h: kBuildWideTree); boxes moved outwards like the binary stream's
         std::vector<rtx::WideNode> w = p.wide;
         for (rtx::WideNode &n : w)
@@ -164,7 +163,7 @@ int upload_all(RtxScene *scene, DeviceState &st)
 // what upload_all allocated so far goes back when it fails half way (the caller may retry: nothing may leak)
 void release_uploads(DeviceState &st)
 {
-    void **bufs[] = {&st.nodes, &st.nodes16, &st.wide, &st.ref_nodes, &st.tris, &st.shade, &st.samples, &st.lights, &st.thr, &st.planes, &st.light_boxes,
+    void **bufs[] = {&st.nodes, &st.wide, &st.ref_nodes, &st.tris, &st.shade, &st.samples, &st.lights, &st.thr, &st.planes, &st.light_boxes,
                      reinterpret_cast<void **>(&st.d_counters)};
     for (void **b : bufs) {
         if (*b) (void)hipFree(*b);
@@ -192,7 +191,6 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     const rtx::PreparedScene &p = scene->prep;
     rtx::DeviceScene S;
     S.nodes = static_cast<const rtx::NodeRec *>(st.nodes);
-    S.nodes16 = static_cast<const rtx::Node16 *>(st.nodes16);
     S.wide = static_cast<const rtx::WideNode *>(st.wide);
     S.n_wide = static_cast<uint32_t>(p.wide.size());
     S.ref_nodes = static_cast<const rtx::NodeRec *>(st.ref_nodes);
@@ -396,7 +394,7 @@ void rtx_scene_destroy(RtxScene *scene)
         DeviceGuard g(kv.first);
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
-        void *bufs[] = {st.nodes, st.nodes16, st.wide, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.light_boxes, st.d_out, st.d_counters, st.d_redo,
+        void *bufs[] = {st.nodes, st.wide, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.light_boxes, st.d_out, st.d_counters, st.d_redo,
                         st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr, st.ws.buckets, st.ws.cut};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);

@@ -631,7 +631,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 {
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    const Node16 RTX_CONSTANT *nodes16 = (const Node16 RTX_CONSTANT *)S.nodes16;
     // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no barrier; LDS only inside shaft_cut)
     __shared__ uint32_t l_front_all[RTX_PROBE_WAVES][128];   // the cut's next frontier: node, subtree size
 #if RTX_ABLATION
@@ -671,9 +670,9 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 #elif RTX_ABLATION
     const bool ok = (S.j1_mode == 2u || S.j1_mode == 3u)
         ? j1_closest_hit_blocks<COUNT>(S.j1_mode, S.tris, S.shade, S.n_prims, pr, wc, lane, l_j1_block[wave_in_group])
-        : closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global, false, nodes16);               // main.rs:187
+        : closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);               // main.rs:187
 #else
-    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global, false, nodes16);   // main.rs:187
+    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
 #endif
 #if RTX_EXPERIMENT_PROBE_PHASES
     const unsigned long long pp_t1 = wall_clock64();
@@ -754,7 +753,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
             LaneRay sr = make_ray(hit, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);
             sr.limit = dist_light;
             WaveCounters probe;
-            (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global, false, nodes16);
+            (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
             weight = (uint32_t)(probe.node_visits + probe.tri_visits);
         }
 #endif
@@ -1014,7 +1013,6 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
 #endif
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    const Node16 RTX_CONSTANT *nodes16 = (const Node16 RTX_CONSTANT *)S.nodes16;
     // the first global triangle's plane, fetched once (rtx_traverse.hpp: plane_rules_out)
     const TriRec RTX_CONSTANT *planes = (const TriRec RTX_CONSTANT *)S.planes;
     const bool have_plane = RTX_PLANE_SHORTCUT && planes != nullptr;
@@ -1281,13 +1279,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             else
 #endif
                             if (whole_tree)
-                                ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground, nodes16);
+                                ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);
 #if RTX_ABLATION
                             else if (S.j1_mode == 1u)
                                 ok = j1_any_hit_cut_vec<COUNT, SPHERES>(S.nodes, nodes, tris, S.shade, l_cut, n_cut, l_j1_win, sr.ray, wc, S.n_global, no_ground);
 #endif
                             else
-                                ok = any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground, nodes16);
+                                ok = any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);
                         }
 #endif
                         if (!ok && lane == 0) l_ctl[1] = 1u;
@@ -1592,7 +1590,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
-    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_HALF_STREAM)
+    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD)

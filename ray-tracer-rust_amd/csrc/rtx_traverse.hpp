@@ -939,155 +939,6 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
     visits = n;
 }
 
-// The same over the HALF-SIZE stream (scene_prep.h: Node16): a record is one s_load_dwordx4 into s[64:67] — six binary16
-// planes in three words, the fourth the skip offset (inner node, in bytes already) or the leaf word — and a plane enters its
-// fused multiply-add as it is, v_fma_mix_f32 taking the named half of a scalar register as an f16 operand beside the ray's
-// f32 constants: the same ten (general: sixteen) vector instructions at the same rate (tools/valu_rate.hip), half the
-// bytes through the scalar cache, and one scalar instruction fewer where a subtree is skipped.  off / end are byte offsets
-// into THIS stream (16 x index).  On return info = the leaf's word (bit 31 set; count and first record inside) or 0.
-#define RTX_H_LO " op_sel_hi:[1,0,0]"
-#define RTX_H_HI " op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-template <bool COUNT>
-__device__ __forceinline__ void advance_to_leaf16(const Node16 RTX_CONSTANT *__restrict__ nodes16, uint32_t &off, uint32_t end,
-                                                  unsigned long long alive, const LaneRay &r, uint32_t oct, uint32_t &info,
-                                                  uint32_t &visits)
-{
-    float a, b, c, d, e, f, g;
-    unsigned long long m;
-    uint32_t nxt;
-    uint32_t o = off, w3, n = visits;
-    const float px = -r.nx, py = -r.ny, pz = -r.nz;
-    // record halves: s64 lo.x | lo.y   s65 lo.z | hi.x   s66 hi.y | hi.z   s67 skip offset / leaf word
-#define RTX_BOX16_OCTANT(NX, NXH, FX, FXH, NY, NYH, FY, FYH, NZ, NZH, FZ, FZH)                                            \
-        "v_fma_mix_f32 %[a], " NX ", %[ix], -%[px]" NXH "\n\t"                                                            \
-        "v_fma_mix_f32 %[b], " FX ", %[ix], -%[px]" FXH "\n\t"                                                            \
-        "v_fma_mix_f32 %[c], " NY ", %[iy], -%[py]" NYH "\n\t"                                                            \
-        "v_fma_mix_f32 %[d], " FY ", %[iy], -%[py]" FYH "\n\t"                                                            \
-        "v_fma_mix_f32 %[e], " NZ ", %[iz], -%[pz]" NZH "\n\t"                                                            \
-        "v_fma_mix_f32 %[f], " FZ ", %[iz], -%[pz]" FZH "\n\t"                                                            \
-        "v_max_f32 %[e], 0, %[e]\n\t"                                                                                    \
-        "v_max3_f32 %[a], %[a], %[c], %[e]\n\t"                                                                          \
-        "v_min3_f32 %[b], %[b], %[d], %[f]\n\t"                                                                          \
-        "v_cmp_ngt_f32 vcc, %[a], %[b]\n\t"
-#define RTX_BOX16_GENERAL                                                                                                \
-        "v_fma_mix_f32 %[a], s64, %[ix], -%[px]" RTX_H_LO "\n\t"                                                          \
-        "v_fma_mix_f32 %[b], s65, %[ix], -%[px]" RTX_H_HI "\n\t"                                                          \
-        "v_fma_mix_f32 %[c], s64, %[iy], -%[py]" RTX_H_HI "\n\t"                                                          \
-        "v_fma_mix_f32 %[d], s66, %[iy], -%[py]" RTX_H_LO "\n\t"                                                          \
-        "v_fma_mix_f32 %[e], s65, %[iz], -%[pz]" RTX_H_LO "\n\t"                                                          \
-        "v_fma_mix_f32 %[f], s66, %[iz], -%[pz]" RTX_H_HI "\n\t"                                                          \
-        "v_min_f32 %[g], %[a], %[b]\n\t"                                                                                 \
-        "v_max_f32 %[a], %[a], %[b]\n\t"                                                                                 \
-        "v_min_f32 %[b], %[c], %[d]\n\t"                                                                                 \
-        "v_max_f32 %[c], %[c], %[d]\n\t"                                                                                 \
-        "v_min_f32 %[d], %[e], %[f]\n\t"                                                                                 \
-        "v_max_f32 %[e], %[e], %[f]\n\t"                                                                                 \
-        "v_max3_f32 %[g], %[g], %[b], %[d]\n\t"                                                                          \
-        "v_min3_f32 %[a], %[a], %[c], %[e]\n\t"                                                                          \
-        "v_cmp_ngt_f32 vcc, %[g], %[a]\n\t"                                                                              \
-        "v_cmp_ngt_f32 %[m], 0, %[a]\n\t"                                                                                \
-        "s_and_b64 vcc, vcc, %[m]\n\t"
-#define RTX_ADVANCE16_LOOP(K, COUNT_LINE, BOX)                                                                           \
-        ".Lloop" K "_%=:\n\t"                                                                                            \
-        "s_load_dwordx4 s[64:67], %[base], %[off]\n\t"                                                                   \
-        COUNT_LINE                                                                                                       \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
-        "s_add_u32 %[nxt], %[off], 16\n\t"                                                                               \
-        BOX                                                                                                              \
-        "s_and_b64 vcc, vcc, %[alive]\n\t"                                                                               \
-        "s_cbranch_scc0 .Lnone" K "_%=\n\t"                                                                              \
-        "s_cmp_lt_i32 s67, 0\n\t"                                                                                        \
-        "s_cbranch_scc1 .Lout%=\n\t"                                                                                     \
-        "s_mov_b32 %[off], %[nxt]\n\t"                                                                                   \
-        "s_branch .Lloop" K "_%=\n"                                                                                       \
-        ".Lnone" K "_%=:\n\t"                                                                                            \
-        "s_cmp_lt_i32 s67, 0\n\t"                                                                                        \
-        "s_cselect_b32 %[off], %[nxt], s67\n\t"                                                                          \
-        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                \
-        "s_cbranch_scc1 .Lloop" K "_%=\n\t"                                                                              \
-        "s_branch .Lend%=\n"
-    // x: near = lo.x (s64 lo) when the component is positive, else hi.x (s65 hi); y: lo.y (s64 hi) / hi.y (s66 lo); z: lo.z (s65 lo) / hi.z (s66 hi)
-#define RTX_XP "s64", RTX_H_LO, "s65", RTX_H_HI
-#define RTX_XN "s65", RTX_H_HI, "s64", RTX_H_LO
-#define RTX_YP "s64", RTX_H_HI, "s66", RTX_H_LO
-#define RTX_YN "s66", RTX_H_LO, "s64", RTX_H_HI
-#define RTX_ZP "s65", RTX_H_LO, "s66", RTX_H_HI
-#define RTX_ZN "s66", RTX_H_HI, "s65", RTX_H_LO
-#define RTX_BOX16(X, Y, Z) RTX_BOX16_OCTANT_(X, Y, Z)
-#define RTX_BOX16_OCTANT_(a1, a2, a3, a4, b1, b2, b3, b4, c1, c2, c3, c4) RTX_BOX16_OCTANT(a1, a2, a3, a4, b1, b2, b3, b4, c1, c2, c3, c4)
-#define RTX_ADVANCE16_BODY(COUNT_LINE)                                                                                   \
-        "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                \
-        "s_cbranch_scc0 .Lend%=\n\t"                                                                                     \
-        "s_bitcmp1_b32 %[oct], 3\n\t"                                                                                    \
-        "s_cbranch_scc1 .Lloop8_%=\n\t"                                                                                  \
-        "s_bitcmp1_b32 %[oct], 2\n\t"                                                                                    \
-        "s_cbranch_scc1 .Lz%=\n\t"                                                                                       \
-        "s_bitcmp1_b32 %[oct], 1\n\t"                                                                                    \
-        "s_cbranch_scc1 .Ly0%=\n\t"                                                                                      \
-        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
-        "s_cbranch_scc1 .Lloop1_%=\n\t"                                                                                  \
-        "s_branch .Lloop0_%=\n"                                                                                          \
-        ".Ly0%=:\n\t"                                                                                                    \
-        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
-        "s_cbranch_scc1 .Lloop3_%=\n\t"                                                                                  \
-        "s_branch .Lloop2_%=\n"                                                                                          \
-        ".Lz%=:\n\t"                                                                                                     \
-        "s_bitcmp1_b32 %[oct], 1\n\t"                                                                                    \
-        "s_cbranch_scc1 .Ly1%=\n\t"                                                                                      \
-        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
-        "s_cbranch_scc1 .Lloop5_%=\n\t"                                                                                  \
-        "s_branch .Lloop4_%=\n"                                                                                          \
-        ".Ly1%=:\n\t"                                                                                                    \
-        "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
-        "s_cbranch_scc1 .Lloop7_%=\n\t"                                                                                  \
-        "s_branch .Lloop6_%=\n"                                                                                          \
-        RTX_ADVANCE16_LOOP("0", COUNT_LINE, RTX_BOX16(RTX_XP, RTX_YP, RTX_ZP))                                           \
-        RTX_ADVANCE16_LOOP("1", COUNT_LINE, RTX_BOX16(RTX_XN, RTX_YP, RTX_ZP))                                           \
-        RTX_ADVANCE16_LOOP("2", COUNT_LINE, RTX_BOX16(RTX_XP, RTX_YN, RTX_ZP))                                           \
-        RTX_ADVANCE16_LOOP("3", COUNT_LINE, RTX_BOX16(RTX_XN, RTX_YN, RTX_ZP))                                           \
-        RTX_ADVANCE16_LOOP("4", COUNT_LINE, RTX_BOX16(RTX_XP, RTX_YP, RTX_ZN))                                           \
-        RTX_ADVANCE16_LOOP("5", COUNT_LINE, RTX_BOX16(RTX_XN, RTX_YP, RTX_ZN))                                           \
-        RTX_ADVANCE16_LOOP("6", COUNT_LINE, RTX_BOX16(RTX_XP, RTX_YN, RTX_ZN))                                           \
-        RTX_ADVANCE16_LOOP("7", COUNT_LINE, RTX_BOX16(RTX_XN, RTX_YN, RTX_ZN))                                           \
-        RTX_ADVANCE16_LOOP("8", COUNT_LINE, RTX_BOX16_GENERAL)                                                           \
-        ".Lend%=:\n\t"                                                                                                   \
-        "s_mov_b32 s67, 0\n"                                                                                             \
-        ".Lout%=:"
-    if (COUNT) {
-        asm volatile(RTX_ADVANCE16_BODY("s_add_u32 %[n], %[n], 1\n\t")
-                     : [off] "+s"(o), [n] "+s"(n), [nxt] "=&s"(nxt), [m] "=&s"(m), "={s67}"(w3),
-                       [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
-                     : [base] "s"(nodes16), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),
-                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
-                     : "vcc", "scc", "s64", "s65", "s66");
-    } else {
-        asm volatile(RTX_ADVANCE16_BODY("")
-                     : [off] "+s"(o), [nxt] "=&s"(nxt), [m] "=&s"(m), "={s67}"(w3),
-                       [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
-                     : [base] "s"(nodes16), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),
-                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
-                     : "vcc", "scc", "s64", "s65", "s66");
-    }
-#undef RTX_ADVANCE16_BODY
-#undef RTX_BOX16_OCTANT_
-#undef RTX_BOX16
-#undef RTX_XP
-#undef RTX_XN
-#undef RTX_YP
-#undef RTX_YN
-#undef RTX_ZP
-#undef RTX_ZN
-#undef RTX_ADVANCE16_LOOP
-#undef RTX_BOX16_GENERAL
-#undef RTX_BOX16_OCTANT
-    asm volatile("" : "+s"(o), "+s"(w3), "+s"(n));   // (pins the scalar results: see advance_to_leaf)
-    off = o;
-    info = w3;
-    visits = n;
-}
-#undef RTX_H_LO
-#undef RTX_H_HI
-
 // The walk over the records [i, end) with the multiply-based test, its box records stepped by advance_to_leaf; what
 // walk_range<.., USE_FAST = true> does, record for record.
 template <bool COUNT, bool SPHERES, bool ANYHIT>
@@ -1096,35 +947,13 @@ __device__ __forceinline__ unsigned long long walk_range_fast(const NodeRec RTX_
                                                               const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
                                                               LaneRay &r, unsigned long long alive,
                                                               unsigned long long &n_active, WaveCounters &wc,
-                                                              uint32_t oct_known = kNone, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                                              uint32_t oct_known = kNone)
 {
     // (readfirstlane: wave-uniform values, but where the compiler has merged them over branches it may hold them in vector
     //  registers, which an "s" operand of the assembly cannot take)
     uint32_t off = __builtin_amdgcn_readfirstlane(i << 5);
     const uint32_t end_off = __builtin_amdgcn_readfirstlane(end << 5);
     const uint32_t oct = oct_known != kNone ? oct_known : walk_octant(r, alive);     // (the lanes walking later are among these)
-    if (nodes16 != nullptr) {      // the half-size stream: the same records at 16 bytes each (advance_to_leaf16)
-        off >>= 1;
-        const uint32_t end16 = end_off >> 1;
-        for (;;) {
-            uint32_t info, visits = 0u;
-            advance_to_leaf16<COUNT>(nodes16, off, end16, alive, r, oct, info, visits);
-            if (COUNT) { wc.box_tests += n_active * visits; wc.node_visits += visits; }
-            if (info == 0u) break;
-            const uint32_t first = info & kLeaf16FirstMask, count = (info >> kLeaf16CountShift) & kLeaf16MaxCount;
-            if (SPHERES && (info & kSphereFlag))
-                leaf_spheres<COUNT, ANYHIT>(tris, shade, first, count, r, n_active, wc);
-            else
-                leaf_triangles<COUNT, ANYHIT, true>(tris, shade, first, count, r, alive, n_active, wc);
-            if (ANYHIT) {
-                alive = ballot(r.active);
-                if (alive == 0ull) break;
-                if (COUNT) n_active = __popcll(alive);
-            }
-            off += 16u;
-        }
-        return alive;
-    }
     for (;;) {
         uint32_t link, info, visits = 0u;
         advance_to_leaf<COUNT>(nodes, off, end_off, alive, r, oct, link, info, visits);
@@ -1153,10 +982,10 @@ __device__ __forceinline__ unsigned long long walk_range(const NodeRec RTX_CONST
                                                          const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
                                                          LaneRay &r, unsigned long long alive,
                                                          unsigned long long &n_active, WaveCounters &wc,
-                                                         uint32_t oct_known = kNone, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                                         uint32_t oct_known = kNone)
 {
 #if RTX_ASM_WALK && RTX_CULL_FMA && RTX_CULL_INFLATED && !RTX_CULL_PACKED
-    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc, oct_known, nodes16);
+    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc, oct_known);
 #endif
     while (i < end) {
 #if RTX_ASM_NODE_LOAD
@@ -1218,7 +1047,7 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
                                             unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
-                                            uint32_t n_global, uint32_t first_global = 0u, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                            uint32_t n_global, uint32_t first_global = 0u)
 {
     // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
     // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
@@ -1235,7 +1064,7 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
         }
         i = 2u;
     }
-    (void)walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, i, n_nodes, r, alive, n_active, wc, kNone, nodes16);
+    (void)walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, i, n_nodes, r, alive, n_active, wc);
 }
 
 // SPHERES = false compiles the Sphere arm out: scenes without spheres (every BASELINE configuration) run the
@@ -1245,7 +1074,7 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                             LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
-                                            bool first_global_ruled_out = false, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                            bool first_global_ruled_out = false)
 {
     unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
     // direction classes: six compares voted one by one (direction_is_regular); the hard test runs only when some
@@ -1261,7 +1090,7 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
     // the choice inside the loop every node paid two more taken branches on the scalar unit)
     if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true, LEAN>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global,
-                                                            (first_global_ruled_out && n_global != 0u) ? 1u : 0u, nodes16);
+                                                            (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
     else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
     return true;
 }
@@ -1273,9 +1102,9 @@ __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__
                                         const TriRec RTX_CONSTANT *__restrict__ tris,
                                         const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                         LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
-                                        bool first_global_ruled_out = false, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                        bool first_global_ruled_out = false)
 {
-    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out, nodes16);
+    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
 }
 
 // ---- the wide walk (A/B builds only: -DRTX_WIDE_WALK=1 / -DRTX_PROBE_WIDE=1; librtx.so walks the binary stream) -------
@@ -1433,7 +1262,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
                                          const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
                                          uint32_t n_cut, LaneRay &r, unsigned long long alive,
                                          unsigned long long n_active, WaveCounters &wc, uint32_t n_global,
-                                         uint32_t first_global, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                         uint32_t first_global)
 {
     if (n_global != 0u) {   // the global triangles (the ground): every walk tests them, without a box test
         leaf_triangles<COUNT, true, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
@@ -1466,7 +1295,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
             if (COUNT) n_active = __popcll(alive);
         } else {
             const uint32_t begin = __builtin_amdgcn_readfirstlane(e[0]), end = __builtin_amdgcn_readfirstlane(e[1]);
-            alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc, oct, nodes16);
+            alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc, oct);
         }
         if (alive == 0ull) break;
     }
@@ -1477,7 +1306,7 @@ __device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
                                             uint32_t n_cut, LaneRay &r, WaveCounters &wc, uint32_t n_global,
-                                            bool first_global_ruled_out, const Node16 RTX_CONSTANT *nodes16 = nullptr)
+                                            bool first_global_ruled_out)
 {
     const unsigned long long alive = ballot(r.active);
     const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
@@ -1489,7 +1318,7 @@ __device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restri
     if (COUNT) n_active = __popcll(alive);
     if (FAST && all_regular)
         walk_cut<COUNT, SPHERES, true, LEAN>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global,
-                                             (first_global_ruled_out && n_global != 0u) ? 1u : 0u, nodes16);
+                                             (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
     else
         walk_cut<COUNT, SPHERES, false, false>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global, 0u);
     return true;

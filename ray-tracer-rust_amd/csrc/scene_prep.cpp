@@ -248,116 +248,6 @@ int ref_leaf_rank(uint32_t n, const float *v0v1v2, uint32_t *out_rank)
 }
 
 // --------------------------------------------------------------------------
-// binary16 with directed rounding (scene_prep.h: Node16).  Conversion by hand: no dependence on the host's half type.
-float half_bits_to_float(uint16_t h)
-{
-    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
-    uint32_t bits;
-    if (e == 0u) {
-        if (m == 0u) {
-            bits = sign;
-        } else {                                  // subnormal: m * 2^-24
-            const float v = std::ldexp(static_cast<float>(m), -24);
-            std::memcpy(&bits, &v, 4);
-            bits |= sign;
-        }
-    } else if (e == 31u) {
-        bits = sign | 0x7F800000u | (m << 13);
-    } else {
-        bits = sign | ((e + 112u) << 23) | (m << 13);
-    }
-    float f;
-    std::memcpy(&f, &bits, 4);
-    return f;
-}
-
-namespace {
-// the half nearest below-or-equal in MAGNITUDE (truncation), for finite x; exact flag tells whether x is that half
-uint16_t half_truncate(float x, bool &exact)
-{
-    uint32_t bits;
-    std::memcpy(&bits, &x, 4);
-    const uint16_t sign = static_cast<uint16_t>((bits >> 16) & 0x8000u);
-    const int32_t e = static_cast<int32_t>((bits >> 23) & 0xFFu) - 127;
-    const uint32_t m = bits & 0x7FFFFFu;
-    if (e > 15) { exact = false; return sign | 0x7BFFu; }                  // beyond 65504: the largest finite half
-    if (e < -14) { exact = (bits & 0x7FFFFFFFu) == 0u; return sign; }      // below the normal range: zero
-    exact = (m & 0x1FFFu) == 0u;
-    return static_cast<uint16_t>(sign | ((e + 15) << 10) | (m >> 13));
-}
-// one step away from zero in magnitude (never leaves a subnormal: from zero the step is to the smallest NORMAL)
-uint16_t half_grow(uint16_t h)
-{
-    const uint16_t sign = h & 0x8000u, mag = h & 0x7FFFu;
-    if (mag == 0u) return sign | 0x0400u;
-    if (mag >= 0x7BFFu) return sign | 0x7C00u;                             // infinity
-    return sign | static_cast<uint16_t>(mag + 1u);
-}
-}  // namespace
-
-uint16_t half_round_down(float x)
-{
-    bool exact;
-    const uint16_t t = half_truncate(x, exact);
-    if (exact) return (t & 0x7FFFu) == 0u ? 0u : t;                        // (-0 -> +0)
-    return x > 0.0f ? t : half_grow(t);                                    // positive: towards zero is down; negative: away is down
-}
-
-uint16_t half_round_up(float x)
-{
-    bool exact;
-    const uint16_t t = half_truncate(x, exact);
-    if (exact) return (t & 0x7FFFu) == 0u ? 0u : t;
-    if (x > 0.0f) return half_grow(t);
-    return (t & 0x7FFFu) == 0u ? 0u : t;                                   // negative: towards zero is up
-}
-
-void build_half_stream(PreparedScene &s)
-{
-    s.nodes16.clear();
-    if (!RTX_HALF_STREAM) return;
-    const size_t n = s.nodes.size();
-    if (n == 0 || n * sizeof(Node16) >= (1ull << 31) || s.tris.size() > kLeaf16FirstMask) return;
-    // does binary16 resolve this scene?  A plane at p moves by at most 2^-11 |p| (one step of the format) plus cull_delta
-    // again; that must stay small against the leaves' own boxes or the test accepts everything nearby.  Criterion: the
-    // step at the tree's largest coordinate is at most 1/8 of the mean leaf extent (sum of the three sides / 3).
-    const uint32_t proper = s.n_global != 0u ? 2u : 0u;
-    double extent_sum = 0.0, coord_max = 0.0;
-    size_t leaves = 0;
-    for (size_t i = proper; i < n; ++i) {
-        const NodeRec &nd = s.nodes[i];
-        for (int k = 0; k < 3; ++k) coord_max = std::fmax(coord_max, std::fmax(std::fabs(nd.bmin[k]), std::fabs(nd.bmax[k])));
-        if (!(nd.info & kLeafFlag)) continue;
-        if (nd.link > kLeaf16MaxCount) return;
-        for (int k = 0; k < 3; ++k) extent_sum += double(nd.bmax[k]) - nd.bmin[k];
-        ++leaves;
-    }
-    if (leaves == 0 || !(coord_max < 60000.0)) return;
-    const double step = std::ldexp(1.0, std::ilogb(std::fmax(coord_max, 1e-30)) - 10);      // spacing of halves at coord_max
-    if (!(step <= (extent_sum / (3.0 * double(leaves))) / 8.0)) return;
-    s.nodes16.resize(n);
-    const float out = 2.0f * s.cull_delta;             // the 32-byte device stream's shift, and once more for this test's own roundings
-    for (size_t i = 0; i < n; ++i) {
-        const NodeRec &nd = s.nodes[i];
-        Node16 r;
-        if (i < proper) {                              // the root and the global primitives' leaf are never walked: boxes that accept
-            r.w[0] = 0xFC00FC00u; r.w[1] = 0x7C00FC00u; r.w[2] = 0x7C007C00u;      // (-inf, -inf, -inf) .. (+inf, +inf, +inf)
-        } else {
-            const uint16_t lx = half_round_down(nd.bmin[0] - out), ly = half_round_down(nd.bmin[1] - out), lz = half_round_down(nd.bmin[2] - out);
-            const uint16_t hx = half_round_up(nd.bmax[0] + out), hy = half_round_up(nd.bmax[1] + out), hz = half_round_up(nd.bmax[2] + out);
-            r.w[0] = lx | (uint32_t(ly) << 16);
-            r.w[1] = lz | (uint32_t(hx) << 16);
-            r.w[2] = hy | (uint32_t(hz) << 16);
-        }
-        if (nd.info & kLeafFlag)
-            r.w[3] = kLeafFlag | (nd.info & kSphereFlag) | (nd.link << kLeaf16CountShift) | (nd.info & kLeaf16FirstMask);
-        else
-            r.w[3] = nd.link << 4;
-        s.nodes16[i] = r;
-    }
-}
-
-// --------------------------------------------------------------------------
 // Acceleration structure for the kernel: binned-SAH BVH over the triangles' exact
 // AABBs, flattened in pre-order with skip links.  Its shape is free: the reference
 // visits every node whose box test passes and counts a leaf only when the leaf's own
@@ -995,7 +885,6 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                              : std::numeric_limits<float>::infinity();
             g.idx = t.idx;
         }
-        build_half_stream(s);
         for (NodeRec &nd : s.ref_nodes)   // leaves of the reference stream point at the same record array
             if (nd.info & kLeafFlag) {
                 const uint32_t prim = nd.info & kLeafIndexMask;

@@ -83,26 +83,6 @@ constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kSphereFlag = 0x40000000u;
 constexpr uint32_t kLeafIndexMask = 0x3FFFFFFFu;
 
-// The HALF-SIZE stream of the walks' multiply-based box test: the same tree, the same pre-order positions, 16 bytes per
-// record — six planes as binary16 (IEEE half), rounded OUTWARDS from the planes the 32-byte device stream carries
-// (already moved out by cull_delta), and one word:
-//   w0 = lo.x | lo.y << 16    w1 = lo.z | hi.x << 16    w2 = hi.y | hi.z << 16
-//   w3 = inner node: BYTE offset (16 x index) of the record to continue with when the subtree is skipped, bit 31 clear
-//        leaf:       kLeafFlag | kSphereFlag? | records << kLeaf16CountShift | first primitive record
-// A box test only has to keep a SUPERSET of what the reference's test accepts, so a plane may lie further out; half the
-// bytes per record is twice the records per line of the 16 KB scalar cache the walks live on (four, and a node's first
-// child is the next record) and four scalar registers per record instead of eight.  The kernel's test takes the halves as
-// they are (v_fma_mix_f32: one f16 operand, f32 arithmetic — the ray's constants are the f32 ones).  Built when every
-// leaf has at most kLeaf16MaxCount records, the primitives fit kLeaf16FirstMask and binary16 resolves the scene: a plane at
-// coordinate p lies within 2^-11 |p| of where it was, which must be small against the boxes of the leaves; else the
-// vector is empty and the walks read the 32-byte stream.
-constexpr uint32_t kLeaf16CountShift = 25u, kLeaf16MaxCount = 31u, kLeaf16FirstMask = (1u << kLeaf16CountShift) - 1u;
-struct Node16 { uint32_t w[4]; };
-static_assert(sizeof(Node16) == 16, "Node16 must be 16 bytes");
-#ifndef RTX_HALF_STREAM
-#define RTX_HALF_STREAM 1
-#endif
-
 // One triangle as the traversal consumes it: 16 dwords, one scalar 64-byte load.
 // v0,e1,e2 are the 36 bytes Möller–Trumbore reads (triangle.rs:66-94); bmin/bmax are the
 // triangle's own AABB (triangle.rs:45-56), needed because the reference only counts a leaf
@@ -144,7 +124,6 @@ struct PreparedScene {
     std::vector<WideNode> wide;        // A/B builds only (kBuildWideTree): the same tree with four children per node (may be
                                        // empty: a scene of global triangles only); wide[0] is the root.  Else empty.
     uint32_t wide_depth = 0;           // levels of wide nodes
-    std::vector<Node16>   nodes16;     // the half-size stream (see Node16), or empty
     std::vector<NodeRec>  ref_nodes;   // the reference's own tree as a stream (empty when not built)
     std::vector<TriRec>   tris;        // primitive records (triangles and spheres) in leaf order
     std::vector<ShadeRec> shade;       // in caller order
@@ -176,14 +155,6 @@ int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);
 // the number of wide levels.  A root that is a leaf gives one wide node with one child.
 // prim_boxes: n x {lo xyz, hi xyz} of the primitive records in leaf order (to bound the runs of a large leaf).
 uint32_t wide_nodes_build(const std::vector<NodeRec> &nodes, uint32_t root, const float *prim_boxes, std::vector<WideNode> &out);
-
-// binary16 bits of the greatest half <= x (down) / the least half >= x (up); never a subnormal (they round on outwards to
-// the next normal or to zero), +-infinity beyond the format's range.  x finite.
-uint16_t half_round_down(float x);
-uint16_t half_round_up(float x);
-float half_bits_to_float(uint16_t h);
-// fills s.nodes16 from s.nodes and s.cull_delta (or leaves it empty: see Node16)
-void build_half_stream(PreparedScene &s);
 
 // ---- pieces with their own tests ----
 void camera_new(const float eye[3], const float look_at[3], const float up[3],
