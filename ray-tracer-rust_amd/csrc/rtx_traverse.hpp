@@ -443,7 +443,7 @@ constexpr bool kTriangleEarlyOut = RTX_TRIANGLE_EARLY_OUT != 0;
 // the division; lanes with |x| < 1e-5 never use the value (triangle.rs:73).
 __device__ __forceinline__ float reciprocal_ieee(float x)
 {
-    if (ballot(fabsf(x) > 0x1p126f) != 0ull) return 1.0f / x;
+    if (__builtin_expect(ballot(fabsf(x) > 0x1p126f) != 0ull, 0)) return 1.0f / x;    // (unlikely: keeps the short way the fall-through)
     const float y0 = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, y0, 1.0f);
     return __builtin_fmaf(y0, e, y0);
@@ -592,6 +592,7 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
                                                LaneRay &r, unsigned long long alive, unsigned long long n_active,
                                                WaveCounters &wc)
 {
+    const bool was_active = r.active;
     for (uint32_t k = 0; k < count; ++k) {
 #if RTX_ABLATION && RTX_ASM_TRI_LOAD
         const TriRec rec = VEC ? load_tri_vec(tris, first + k) : load_tri_at(tris, first + k);
@@ -627,11 +628,14 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
         const bool out_v = v < 0.0f || u + v > 1.0f;                                 // :86
         const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;                   // :92
         const bool some = !parallel && !out_u && !out_v;
-        if (r.active && some && !(t < 1.0f)) {
+        // (any-hit: a lane that has found its occluder is told by its result, not by a flag changed inside this loop — a
+        //  boolean carried around the loop costs four scalar instructions per record to merge its lane masks; the caller's
+        //  r.active is settled once behind the loop)
+        if (was_active && (!ANYHIT || r.best_idx == kNone) && some && !(t < 1.0f)) {
             if (own_box_passes<FAST_OK>(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2], r)) {
                 const uint32_t idx = tr->idx;
                 if (ANYHIT) {
-                    if (candidate_occludes(r, t)) { r.best_t = t; r.best_idx = idx; r.active = false; }
+                    if (candidate_occludes(r, t)) { r.best_t = t; r.best_idx = idx; }
                 } else {
                     bool take = t < r.best_t;
                     if (!take && t == r.best_t && r.best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
@@ -641,6 +645,7 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
             }
         }
     }
+    if (ANYHIT) r.active = was_active && r.best_idx == kNone;
 }
 
 // The spheres of one leaf against the ray of every lane: Sphere::intersect, then the same leaf rule, leaf box and
