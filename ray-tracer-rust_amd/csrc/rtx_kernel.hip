@@ -1590,7 +1590,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
-    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT)
+    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD)

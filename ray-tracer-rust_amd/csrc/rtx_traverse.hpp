@@ -814,10 +814,21 @@ __device__ __forceinline__ uint32_t walk_octant(const LaneRay &r, unsigned long 
     return 8u;
 #endif
 }
-template <bool COUNT>
+// PRUNE (closest-hit walks): a box is also left out when every walking lane enters it BEYOND the lane's closest hit so
+// far.  The reference never prunes by distance — it takes the minimum over every candidate (bvh.rs:86-132) — but a
+// candidate inside such a box has t >= the box's entry > the lane's best t: it can neither be the minimum nor tie with it
+// (bvh.rs:123-130 is about EQUAL distances), so the result is the same.  Conservatively: the entry computed here lies
+// below the exact one (the stream's planes are moved outwards: box_mask) and `far` is the best t with 2^-16 added relatively
+// (a candidate's t and a box's entry are formed by different roundings of the same geometry: ulps apart at most).  One
+// vector instruction per record (exit = min(exit, far)); what it saves is every record behind the first surface a tile's
+// primary rays meet.
+#ifndef RTX_PRUNE_CLOSEST
+#define RTX_PRUNE_CLOSEST 1
+#endif
+template <bool COUNT, bool PRUNE = false>
 __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__restrict__ nodes, uint32_t &off, uint32_t end,
                                                 unsigned long long alive, const LaneRay &r, uint32_t oct, uint32_t &link,
-                                                uint32_t &info, uint32_t &visits)
+                                                uint32_t &info, uint32_t &visits, float far = 0.0f)
 {
     float a, b, c, d, e, f, g;
     unsigned long long m;
@@ -825,7 +836,7 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
     uint32_t o = off, w6, w7, n = visits;
     const float px = -r.nx, py = -r.ny, pz = -r.nz;   // o * (1/d): the ray keeps these; the step subtracts by operand modifier
     // record words: s64 lo.x  s65 lo.y  s66 hi.x  s67 hi.y  s68 lo.z  s69 hi.z  s70 link  s71 info
-#define RTX_BOX_OCTANT(NX, FX, NY, FY, NZ, FZ)                                                                           \
+#define RTX_BOX_OCTANT(NX, FX, NY, FY, NZ, FZ, PRUNE_B)                                                                  \
         "v_fma_f32 %[a], " NX ", %[ix], -%[px]\n\t"                                                                      \
         "v_fma_f32 %[b], " FX ", %[ix], -%[px]\n\t"                                                                      \
         "v_fma_f32 %[c], " NY ", %[iy], -%[py]\n\t"                                                                      \
@@ -835,8 +846,9 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
         "v_max_f32 %[e], 0, %[e]\n\t"                                                                                    \
         "v_max3_f32 %[a], %[a], %[c], %[e]\n\t"   /* max(entry, 0) */                                                    \
         "v_min3_f32 %[b], %[b], %[d], %[f]\n\t"   /* exit */                                                             \
+        PRUNE_B                                                                                                          \
         "v_cmp_ngt_f32 vcc, %[a], %[b]\n\t"       /* !(max(entry, 0) > exit): a NaN can only accept */
-#define RTX_BOX_GENERAL                                                                                                  \
+#define RTX_BOX_GENERAL(PRUNE_A)                                                                                         \
         "v_fma_f32 %[a], s64, %[ix], -%[px]\n\t"                                                                         \
         "v_fma_f32 %[b], s66, %[ix], -%[px]\n\t"                                                                         \
         "v_fma_f32 %[c], s65, %[iy], -%[py]\n\t"                                                                         \
@@ -851,6 +863,7 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
         "v_max_f32 %[e], %[e], %[f]\n\t"                                                                                 \
         "v_max3_f32 %[g], %[g], %[b], %[d]\n\t"   /* entry */                                                            \
         "v_min3_f32 %[a], %[a], %[c], %[e]\n\t"   /* exit */                                                             \
+        PRUNE_A                                                                                                          \
         "v_cmp_ngt_f32 vcc, %[g], %[a]\n\t"       /* !(entry > exit): a NaN can only accept */                           \
         "v_cmp_ngt_f32 %[m], 0, %[a]\n\t"         /* !(exit < 0) */                                                      \
         "s_and_b64 vcc, vcc, %[m]\n\t"
@@ -875,7 +888,7 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
         "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                \
         "s_cbranch_scc1 .Lloop" K "_%=\n\t"                                                                              \
         "s_branch .Lend%=\n"
-#define RTX_ADVANCE_BODY(COUNT_LINE)                                                                                     \
+#define RTX_ADVANCE_BODY(COUNT_LINE, PB, PA)                                                                             \
         "s_cmp_lt_u32 %[off], %[end]\n\t"                                                                                \
         "s_cbranch_scc0 .Lend%=\n\t"                                                                                     \
         "s_bitcmp1_b32 %[oct], 3\n\t"                                                                                    \
@@ -901,33 +914,48 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
         "s_bitcmp1_b32 %[oct], 0\n\t"                                                                                    \
         "s_cbranch_scc1 .Lloop7_%=\n\t"                                                                                  \
         "s_branch .Lloop6_%=\n"                                                                                          \
-        RTX_ADVANCE_LOOP("0", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s65", "s67", "s68", "s69"))                      \
-        RTX_ADVANCE_LOOP("1", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s65", "s67", "s68", "s69"))                      \
-        RTX_ADVANCE_LOOP("2", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s67", "s65", "s68", "s69"))                      \
-        RTX_ADVANCE_LOOP("3", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s67", "s65", "s68", "s69"))                      \
-        RTX_ADVANCE_LOOP("4", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s65", "s67", "s69", "s68"))                      \
-        RTX_ADVANCE_LOOP("5", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s65", "s67", "s69", "s68"))                      \
-        RTX_ADVANCE_LOOP("6", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s67", "s65", "s69", "s68"))                      \
-        RTX_ADVANCE_LOOP("7", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s67", "s65", "s69", "s68"))                      \
-        RTX_ADVANCE_LOOP("8", COUNT_LINE, RTX_BOX_GENERAL)                                                               \
+        RTX_ADVANCE_LOOP("0", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s65", "s67", "s68", "s69", PB))                      \
+        RTX_ADVANCE_LOOP("1", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s65", "s67", "s68", "s69", PB))                      \
+        RTX_ADVANCE_LOOP("2", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s67", "s65", "s68", "s69", PB))                      \
+        RTX_ADVANCE_LOOP("3", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s67", "s65", "s68", "s69", PB))                      \
+        RTX_ADVANCE_LOOP("4", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s65", "s67", "s69", "s68", PB))                      \
+        RTX_ADVANCE_LOOP("5", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s65", "s67", "s69", "s68", PB))                      \
+        RTX_ADVANCE_LOOP("6", COUNT_LINE, RTX_BOX_OCTANT("s64", "s66", "s67", "s65", "s69", "s68", PB))                      \
+        RTX_ADVANCE_LOOP("7", COUNT_LINE, RTX_BOX_OCTANT("s66", "s64", "s67", "s65", "s69", "s68", PB))                      \
+        RTX_ADVANCE_LOOP("8", COUNT_LINE, RTX_BOX_GENERAL(PA))                                                               \
         ".Lend%=:\n\t"                                                                                                   \
         "s_mov_b32 s71, 0\n"                                                                                             \
         ".Lout%=:"
-    if (COUNT) {
-        asm volatile(RTX_ADVANCE_BODY("s_add_u32 %[n], %[n], 1\n\t")
+#define RTX_ADVANCE_OPERANDS                                                                                             \
+                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),      \
+                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [far] "v"(far)                                    \
+                     : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69"
+#define RTX_PB "v_min_f32 %[b], %[b], %[far]\n\t"
+#define RTX_PA "v_min_f32 %[a], %[a], %[far]\n\t"
+    if (COUNT && PRUNE) {
+        asm volatile(RTX_ADVANCE_BODY("s_add_u32 %[n], %[n], 1\n\t", RTX_PB, RTX_PA)
                      : [off] "+s"(o), [n] "+s"(n), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
                        [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
-                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),
-                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
-                     : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69");
-    } else {
-        asm volatile(RTX_ADVANCE_BODY("")
+                     RTX_ADVANCE_OPERANDS);
+    } else if (PRUNE) {
+        asm volatile(RTX_ADVANCE_BODY("", RTX_PB, RTX_PA)
                      : [off] "+s"(o), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
                        [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
-                     : [base] "s"(nodes), [end] "s"(end), [alive] "s"(alive), [oct] "s"(oct), [ix] "v"(r.ix), [iy] "v"(r.iy),
-                       [iz] "v"(r.iz), [px] "v"(px), [py] "v"(py), [pz] "v"(pz)
-                     : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69");
+                     RTX_ADVANCE_OPERANDS);
+    } else if (COUNT) {
+        asm volatile(RTX_ADVANCE_BODY("s_add_u32 %[n], %[n], 1\n\t", "", "")
+                     : [off] "+s"(o), [n] "+s"(n), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
+                       [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
+                     RTX_ADVANCE_OPERANDS);
+    } else {
+        asm volatile(RTX_ADVANCE_BODY("", "", "")
+                     : [off] "+s"(o), [nxt] "=&s"(nxt), [skip] "=&s"(skip), [m] "=&s"(m), "={s70}"(w6), "={s71}"(w7),
+                       [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g)
+                     RTX_ADVANCE_OPERANDS);
     }
+#undef RTX_PA
+#undef RTX_PB
+#undef RTX_ADVANCE_OPERANDS
 #undef RTX_ADVANCE_BODY
 #undef RTX_ADVANCE_LOOP
 #undef RTX_BOX_GENERAL
@@ -961,7 +989,9 @@ __device__ __forceinline__ unsigned long long walk_range_fast(const NodeRec RTX_
     const uint32_t oct = oct_known != kNone ? oct_known : walk_octant(r, alive);     // (the lanes walking later are among these)
     for (;;) {
         uint32_t link, info, visits = 0u;
-        advance_to_leaf<COUNT>(nodes, off, end_off, alive, r, oct, link, info, visits);
+        // (closest-hit walks: boxes entered beyond the closest hit so far are left out — advance_to_leaf, PRUNE)
+        advance_to_leaf<COUNT, !ANYHIT && RTX_PRUNE_CLOSEST != 0>(nodes, off, end_off, alive, r, oct, link, info, visits,
+                                                                  r.best_t * (1.0f + 0x1p-16f));
         if (COUNT) { wc.box_tests += n_active * visits; wc.node_visits += visits; }
         if (info == 0u) break;
         if (SPHERES && (info & kSphereFlag))

@@ -289,8 +289,8 @@ public:
     // depth_cap: levels the tree may have.  A range that could not be finished within the cap by halving is halved
     // from there on (median split along its widest centroid axis) instead of split by the SAH.
     TreeBuilder(std::vector<Prim> &prims, std::vector<NodeRec> &nodes, uint32_t leaf_max, double box_cost,
-                uint32_t depth_cap = 64u, const float *light = nullptr)
-        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost), depth_cap_(depth_cap), light_(light) {}
+                uint32_t depth_cap = 64u, const float *light = nullptr, bool near_first = false)
+        : prims_(prims), nodes_(nodes), leaf_max_(leaf_max), box_cost_(box_cost), depth_cap_(depth_cap), light_(light), near_first_(near_first) {}
 
     uint32_t leaves = 0, max_leaf = 0, depth = 0;
 
@@ -365,7 +365,8 @@ public:
             for (int k = 0; k < 3; ++k) { const double d = c[k] / double(b - a) - light_[k]; d2 += d * d; }
             return d2;
         };
-        if (!(mean_dist2(begin, mid) < mean_dist2(mid, end))) return mid;     // the first child is the farther one already
+        const bool first_is_nearer = mean_dist2(begin, mid) < mean_dist2(mid, end);
+        if (first_is_nearer == near_first_) return mid;                       // already in the wanted order
         std::rotate(prims_.begin() + begin, prims_.begin() + mid, prims_.begin() + end);
         return begin + (end - mid);
     }
@@ -437,6 +438,7 @@ private:
     double box_cost_;
     uint32_t depth_cap_;
     const float *light_;   // NULL: children in the order the split made them
+    bool near_first_;      // the child nearer to *light_ first (else second)
 };
 
 }  // namespace
@@ -794,7 +796,9 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             // centre of the light points (the first primary ray's): orders the children of every node (TreeBuilder)
             float light_c[3] = {0.0f, 0.0f, 0.0f};
             bool light_ok = RTX_LIGHTWARD_ORDER != 0 && d.nb_light_sample != 0u;
-            if (light_ok) {
+            if (RTX_LIGHTWARD_ORDER == 2) {          // A/B: the child nearer to the EYE first (what pruned primary walks would like)
+                std::memcpy(light_c, d.eye, 12);
+            } else if (light_ok) {
                 double acc[3] = {0, 0, 0};
                 for (uint32_t i = 0; i < d.nb_light_sample; ++i)
                     for (int k = 0; k < 3; ++k) acc[k] += s.light_points[3 * static_cast<size_t>(i) + k];
@@ -805,7 +809,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             }
             auto build_tree = [&](uint32_t depth_cap) {
                 s.nodes.clear();
-                TreeBuilder tb(prims, s.nodes, leaf_max, box_cost, depth_cap, light_ok ? light_c : nullptr);
+                TreeBuilder tb(prims, s.nodes, leaf_max, box_cost, depth_cap, light_ok ? light_c : nullptr, RTX_LIGHTWARD_ORDER == 2);
                 if (s.n_global) {
                     Box g;
                     g.reset();

@@ -30,6 +30,10 @@ for group in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ
     echo "pmc group $i done: $group"
     i=$((i + 1))
 done
+# LDS bank conflicts of the same command: extra LDS-array cycles against all LDS-array cycles
+# (MI355X_MICROARCH.md, LDS); not fatal when the counters are not there
+timeout -k 10 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pmc_lds" -o "$WL" -- \
+    python3 "$ROOT/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-config > "$OUT/pmc_lds.log" 2>&1 && echo "pmc LDS group done" || echo "pmc LDS group failed (see pmc_lds.log)"
 # keep only what the summary needs (the traces of the counted warm-up launches are large)
 find "$OUT" -name "*_agent_info.csv" -delete
 ls -la "$OUT" "$OUT"/pmc0 | head -30
