@@ -378,10 +378,6 @@ __device__ __forceinline__ uint32_t cost_class(unsigned long long cost)
     return k < kCostBuckets ? k : kCostBuckets - 1u;
 }
 
-constexpr uint32_t kTileOpen = 4u;          // TileDesc::flags bit 2: a tile of the open ground (open_ground_kernel's, not a job)
-#ifndef RTX_OPEN_GROUND_KERNEL
-#define RTX_OPEN_GROUND_KERNEL 1
-#endif
 // what a chunk costs before it fetches its first record (ray set-up, the global triangles, its share of the ordered sum),
 // in units of one fetched record: the weight of a tile whose cut is empty
 constexpr uint32_t kChunkFixedCost = 8u;
@@ -704,7 +700,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         }
     }
     float hx = 0.0f, hy = 0.0f, hz = 0.0f;
-    bool grey_lane = true;
     if (hit) {
         const ShadeRec sh = S.shade[pr.best_idx];
         HitRec h;
@@ -715,7 +710,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         h.rgb[0] = sh.rgb[0]; h.rgb[1] = sh.rgb[1]; h.rgb[2] = sh.rgb[2];            // main.rs:191
         h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
         W.hits[(size_t)tile_id * 64u + slot] = h;
-        grey_lane = h.rgb[0] == h.rgb[1] && h.rgb[1] == h.rgb[2] && h.rgb[0] >= 0.0f;
     }
     W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;
     // The tile's cut (shaft_cut above) and, from it, the tile's cost estimate: chunks x (a chunk's fixed work + what a
@@ -764,13 +758,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         }
 #endif
         cost = (unsigned long long)(kChunkFixedCost + weight) * n_chunks;
-        // OPEN GROUND: a full tile of one grey surface whose shaft meets nothing of the tree, in a scene whose only global
-        // primitive has a plane record (the ground of main()) — nothing will be walked for it, every sample is the plane's
-        // certificate and a handful of arithmetic.  Such tiles are not jobs of shade_tiles_kernel: open_ground_kernel takes
-        // them, one wavefront per tile.
-        if (RTX_OPEN_GROUND_KERNEL && n_hit == 64u && (flags & 1u) && n_cut == 0u && S.n_nodes <= S.cut_max_nodes && S.n_global == 1u &&
-            S.planes != nullptr && S.nb_ray == 1u && ballot(!grey_lane) == 0ull)
-            flags |= kTileOpen;
     }
     // A tile without a hit is finished here (main.rs:235: the sums stay as they are), a queued tile belongs to the
     // reference re-render: neither is scheduled for shade_tiles_kernel (cost class kNone).
@@ -787,7 +774,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     }
     if (lane == 0) {
         const bool count_it = !(flags & 2u);
-        const uint32_t key = (sky || (flags & (2u | kTileOpen))) ? kNone : cost_class(cost);
+        const uint32_t key = (sky || (flags & 2u)) ? kNone : cost_class(cost);
 #if RTX_EXPERIMENT_PROBE_PHASES
         const unsigned long long pp_t2 = wall_clock64();
         const uint32_t walk_ticks = (uint32_t)(pp_t1 - pp_t0) > 0xFFFFu ? 0xFFFFu : (uint32_t)(pp_t1 - pp_t0);
@@ -825,8 +812,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 // whose tiles cost more than kSplitShare of a workgroup's fair share of the launch's estimated cost is cut into the
 // power of two of parts that brings it below, at most kMaxTileParts.
 constexpr uint32_t kOrderHist = kCostBuckets, kOrderCursor = 2u * kCostBuckets, kOrderList = 3u * kCostBuckets;
-// [kOrderOpenCount] tiles of the open ground (TileDesc::flags & kTileOpen); their list follows the jobs' region
-constexpr uint32_t kOrderOpenCount = 1u;
 // Who takes which job.  The persistent workgroups b, b + 8, b + 16, ... share an XCD and with it an L2 (workgroups are
 // dealt round-robin over the eight XCDs: MI355X_MICROARCH.md, workgroup dispatch); the order is dealt to these eight
 // groups in runs of kClaimRun consecutive jobs — neighbouring tiles of one cost class, or the parts of one tile — so that
@@ -954,113 +939,6 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
         uint32_t *dst = W.buckets + kOrderList + start[key] + (slot << lg);
         for (uint32_t p = 0; p < (1u << lg); ++p) dst[p] = i | (p << kJobTileBits) | (lg << kJobPartsShift);
     }
-    // the tiles of the open ground: a list of their own behind the jobs' region (n_tiles * kMaxTileParts entries), in no
-    // particular order (they cost the same); a wavefront reserves its tiles' slots with one atomic
-    const bool open = i < n_tiles && (W.tiles[i].flags & kTileOpen) != 0u;
-    const unsigned long long m_open = ballot(open);
-    if (m_open != 0ull) {
-        uint32_t base = 0u;
-        if (lane == (uint32_t)(__ffsll((long long)m_open) - 1)) base = atomicAdd(&W.buckets[kOrderOpenCount], (uint32_t)__popcll(m_open));
-        base = __shfl(base, __ffsll((long long)m_open) - 1);
-        if (open) W.buckets[kOrderList + (size_t)n_tiles * kMaxTileParts + base + (uint32_t)__popcll(m_open & ((1ull << lane) - 1ull))] = i;
-    }
-}
-
-// ---- the open ground ----------------------------------------------------------------------------------------------
-// The tiles probe_kernel marked kTileOpen — full tiles of one grey surface whose shaft meets nothing of the tree, the
-// plane of the scene's only global primitive on record: on big_bunny 4096x4096 they are 96 % of the tiles with a hit and
-// were 81 % of the shading pass — need no walk, no cooperation and no LDS: ONE WAVEFRONT PER TILE, one work-item per
-// pixel, the pixel's hit record in registers, the samples in the reference's own order (main.rs:193-216, i ascending) with
-// the sum carried in a register.  Per sample: the light point (the same for every lane: scalar loads), the exact length
-// and direction (length_and_direction), the "magnitude" half of the ground's certificate (rtx_traverse.hpp:
-// plane_rules_out: these origins lie on the plane), |n.l|, the contribution's division (div_denom's steps) and one
-// addition — about sixty vector instructions, nothing else.  As a job of shade_tiles_kernel such a tile also paid for its
-// records' way through LDS, six workgroup barriers, a hundred results written to and read back from LDS and a claim: 10.4 us
-// of a workgroup for 6.5 SIMD-microseconds of arithmetic.  A sample the short forms do not settle — a lane the
-// certificate does not cover, a direction outside the verified ranges — gets the general treatment on the spot: the
-// global primitives tested by leaf_triangles, the hard-direction refusal (the tile then goes to reference_tiles_kernel).
-// Persistent wavefronts stride over the list order_tiles_kernel left (W.buckets[kOrderOpenCount] entries).
-template <bool COUNT, bool FAST, bool SPHERES>
-__global__ void __launch_bounds__(256, 8) open_ground_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles, StreamWorkspace W,
-                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ queue,
-                                                          unsigned long long *__restrict__ counters)
-{
-    __shared__ float l_thr[256];
-    for (uint32_t k = threadIdx.x; k < 256u; k += 256u) l_thr[k] = S.gamma_thr[k];
-    __syncthreads();
-    const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
-    const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    const TriRec RTX_CONSTANT *planes = (const TriRec RTX_CONSTANT *)S.planes;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_open = W.buckets[kOrderOpenCount];
-    const uint32_t *list = W.buckets + kOrderList + (size_t)n_tiles * kMaxTileParts;
-    TriRec plane0 = {};
-    plane0.v0[0] = planes->v0[0]; plane0.v0[1] = planes->v0[1]; plane0.v0[2] = planes->v0[2];
-    plane0.e1[0] = planes->e1[0]; plane0.e1[1] = planes->e1[1]; plane0.e1[2] = planes->e1[2];
-    plane0.e2[0] = planes->e2[0]; plane0.e2[1] = planes->e2[1]; plane0.e2[2] = planes->e2[2];
-    plane0.bmin[0] = planes->bmin[0];
-    const float denom = (float)(S.nb_ray * S.nb_light);                              // main.rs:211
-    const DenomDiv denom_d = denom_div(denom);
-    WaveCounters wc;
-    for (uint32_t idx = blockIdx.x * 4u + wave; idx < n_open; idx += gridDim.x * 4u) {
-        const uint32_t tile_id = __builtin_amdgcn_readfirstlane(list[idx]);
-        uint32_t tile_x, tile_y;
-        tile_xy(tile_id, tiles_x, RTX_TILE_BLOCKS != 0, tile_x, tile_y);
-        // a full tile: hit record `lane` belongs to pixel `lane` (probe_kernel's compaction is the identity there)
-        const float *h = reinterpret_cast<const float *>(W.hits + (size_t)tile_id * 64u + lane);
-        const float hx = h[0], hy = h[1], hz = h[2], nx = h[3], ny = h[4], nz = h[5], red = h[6];
-        const PlaneOrigin po = plane_origin(plane0, hx, hy, hz);
-        float acc = 0.0f;                                                            // main.rs:182
-        bool redo = false;
-        for (uint32_t i = 0; i < S.nb_light; ++i) {                                  // main.rs:193
-            const float *lp = S.light_points + 3u * i;                               // main.rs:194-196 (hoisted to the host); r = 0
-            const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;           // p - orig
-            float dist_light, sx, sy, sz;
-            const bool short_way = length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);     // main.rs:201-202
-            const float lnd = fabsf(nx * sx + ny * sy + nz * sz);                    // main.rs:207
-            const float x = red * lnd;
-            const float sd = __builtin_fmaf(sz, plane0.e1[2], __builtin_fmaf(sy, plane0.e1[1], sx * plane0.e1[0]));   // plane_magnitude
-            if (short_way && denom_d.usable && ballot(!(po.lhs < fabsf(sd) - plane0.bmin[0])) == 0ull &&
-                ballot(!(x == 0.0f || (x >= 0x1p-60f && x <= 0x1p60f))) == 0ull) {
-                const float q0 = x * denom_d.y;                                      // main.rs:211 by div_denom's steps
-                const float q1 = __builtin_fmaf(__builtin_fmaf(-denom_d.d, q0, x), denom_d.y, q0);
-                acc = acc + __builtin_fmaf(__builtin_fmaf(-denom_d.d, q1, x), denom_d.y, q1);       // main.rs:209-216: lit
-                continue;
-            }
-            // the general treatment of one sample (what a chunk of shade_tiles_kernel does)
-            LaneRay ray = make_ray_bare(true, hx, hy, hz, sx, sy, sz);
-            ray.limit = dist_light;
-            const bool no_ground = ballot(!plane_rules_out(plane0, po, sx, sy, sz)) == 0ull;
-            bool ok;
-            if (no_ground) {
-                ok = short_way || ballot(direction_is_hard(sx, sy, sz)) == 0ull;
-            } else {
-                ray_cull_constants(ray);
-                ok = any_hit_cut<COUNT, FAST, SPHERES, true>(nodes, tris, S.shade, nullptr, 0u, ray, wc, S.n_global, false);   // main.rs:204
-            }
-            if (!ok) { redo = true; break; }
-            const bool lit = ray.best_idx == kNone;                                  // main.rs:219-231
-            acc = acc + (lit ? div_denom(x, denom_d) : 0.0f);                        // (black * 1.0) / denom = +0.0, main.rs:226
-        }
-        if (redo) {     // a hard shadow direction: reference_tiles_kernel redoes the tile and counts its hits
-            if (lane == 0 && !(atomicOr(&W.tiles[tile_id].flags, 2u) & 2u)) {
-                queue[kQueueHeader + atomicAdd(&queue[kQueueRedoCount], 1u)] = tile_id;
-                if (COUNT && counters) {
-                    atomicAdd(&counters[5], 1ull);
-                    atomicAdd(&counters[0], 0ull - (unsigned long long)W.tiles[tile_id].pad);
-                }
-            }
-            continue;
-        }
-        uint32_t px, py, ly;
-        if (tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly)) {
-            const uint8_t q = (uint8_t)quantise(l_thr, acc);                         // grey: one search of the thresholds
-            uint8_t *p = out + ((size_t)ly * S.width + px) * 3u;                     // put_pixel, main.rs:293-294
-            p[0] = q; p[1] = q; p[2] = q;
-        }
-    }
-    if (COUNT && lane == 0) flush_counters<COUNT>(counters, 0ull, wc);
 }
 
 // Without the primary phase the kernel fits the 64 VGPRs of 8 wavefronts per SIMD (4 workgroups per CU): 53 VGPRs, no
@@ -1332,7 +1210,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // loop takes over.  These tiles are bound by their vector instructions: 0.36 ms of a 0.41 ms
                     // ground-only frame, 81 % of big_bunny 4096x4096.
                     uint32_t c_first = wave * 64u;
-#if RTX_OPEN_GROUND_LOOP && !RTX_WIDE_WALK && !RTX_OPEN_GROUND_KERNEL
+#if RTX_OPEN_GROUND_LOOP && !RTX_WIDE_WALK
                     if (!WHOLE && full_tile && grey_tile && n_cut == 0u && have_plane && S.n_global == 1u && denom_d.usable) {
 #if !RTX_FULL_TILE_GENERAL      // the registers are this loop's alone: loaded here, dead behind it
 #pragma unroll
@@ -1601,21 +1479,6 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
         hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
         hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W, grid, split_share());
         if (ev && r == 0u && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;   // end of the scheduling pass
-#if RTX_OPEN_GROUND_KERNEL
-        if (!whole && S.nb_ray == 1u && S.n_global == 1u && S.planes != nullptr) {           // (else no tile is marked)
-            static thread_local int open_dev = -1, open_blocks = 0;
-            if (dev != open_dev) {
-                int per_cu = 0, cus = 0;
-                if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, open_ground_kernel<COUNT, FAST, SPHERES>, 256, 0)) != hipSuccess) return e;
-                if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-                open_blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-                open_dev = dev;
-            }
-            const uint32_t need = (n_tiles + 3u) / 4u;
-            hipLaunchKernelGGL((open_ground_kernel<COUNT, FAST, SPHERES>), dim3(need < (uint32_t)open_blocks ? need : (uint32_t)open_blocks), dim3(256), 0,
-                               stream, S, ts, tiles_x, n_tiles, W, d_out, d_redo, d_counters);
-        }
-#endif
         if (whole)
             hipLaunchKernelGGL((shade_tiles_kernel<COUNT, FAST, NW, SPHERES, true>), dim3(grid), dim3(64 * NW), lds_bytes, stream, S, ts,
                                batch, tiles_x, n_tiles, r, W, d_out, d_redo, d_counters);
@@ -1657,7 +1520,7 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.results = streamed ? pixels * (S.nb_light ? S.nb_light : 1u) * sizeof(float) : 0u;
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);   // streamed (ablation) pipeline only; 16 B
-    b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts + tiles) * sizeof(uint32_t) : 0u;   // header, jobs, open-ground tiles
+    b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts) * sizeof(uint32_t) : 0u;
     b.cut = probe ? tiles * kMaxCut * sizeof(CutEntry) : 0u;
     return b;
 }
@@ -1727,7 +1590,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
-    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_OPEN_GROUND_KERNEL) RTX_SW(RTX_PRUNE_CLOSEST)
+    RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD)
