@@ -59,9 +59,11 @@ def _rank_main(rank, world, port, tile_rows, q):
         # the reductions bench.py performs
         c = bench.reduce_counters(torch.tensor([10 + rank, 1, 2, 3, 4, 0, 0, 0], dtype=torch.int64), world)
         assert c[0] == sum(10 + r for r in range(world)) and c[1] == world
-        el, ks, sched, shade = bench.reduce_times((0.5 + rank, 0.25 * (rank + 1), 0.125, 2.0 - rank), world,
-                                                  torch.device("cpu"))
+        (el, ks, sched, shade), per_rank = bench.reduce_times((0.5 + rank, 0.25 * (rank + 1), 0.125, 2.0 - rank), world,
+                                                              torch.device("cpu"))
         assert el == 0.5 + world - 1 and ks == 0.25 * world and sched == 0.125 and shade == 2.0
+        # every rank's own values beside the maxima (per-device kernel time)
+        assert per_rank == [[0.5 + r, 0.25 * (r + 1), 0.125, 2.0 - r] for r in range(world)]
         if rank == 0:
             frame = np.zeros_like(gold)
             for r in range(world):
