@@ -586,61 +586,6 @@ __device__ __forceinline__ TriRec load_tri_vec(const TriRec RTX_CONSTANT *base, 
 }
 #endif
 
-// A lane remembers what occluded it.  A shadow ray's answer is "SOME accepted candidate occludes" (candidate_occludes):
-// which one, and the order in which the records are tried, is free.  The next ray of a lane — the same pixel towards
-// the next light point (sample-major chunks), or the neighbouring pixel towards the same one (pixel-major) — is most often
-// occluded by the SAME primitive, so each lane keeps the position of that record in the primitive array and tries it
-// before the walk: one record per LANE (vector loads of the lane's own 64 bytes), the expressions of leaf_triangles
-// word for word, the same own-box rule and the same occlusion test.  A wavefront whose lanes are all answered this way
-// does not walk; the others walk with fewer lanes voting.  Measured on the counted frames (profiles/r03/y_*): walks that
-// end with every lane occluded were 30 % of big_bunny 1080p's walks and 48 % / 66 % of its box / primitive record
-// fetches; 40 % / 66 % / 70 % on the 1M-triangle soup.
-// Regular directions only (the caller has checked): own_box_passes<true> needs them.
-#ifndef RTX_REMEMBER_OCCLUDER
-#define RTX_REMEMBER_OCCLUDER 1
-#endif
-#ifndef RTX_EXPERIMENT_UMBRA      // counted frames of a development build: only walks of one outcome are counted
-#define RTX_EXPERIMENT_UMBRA 0
-#endif
-template <bool COUNT>
-__device__ __forceinline__ void test_remembered(const TriRec RTX_CONSTANT *__restrict__ tris, uint32_t n_prims,
-                                                LaneRay &r, uint32_t remembered, WaveCounters &wc)
-{
-    const bool try_it = r.active && remembered < n_prims;      // (kNone, or anything that is not a position: no test)
-    if (COUNT) {
-        const unsigned long long trying = ballot(try_it);
-        if (trying != 0ull) { wc.tri_tests += __popcll(trying); wc.tri_visits += 1; }
-    }
-    if (try_it) {
-        const TriRec RTX_CONSTANT *tr = tris + remembered;
-        const float v0x = tr->v0[0], v0y = tr->v0[1], v0z = tr->v0[2];
-        const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
-        const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
-        const float pvx = r.dy * e2z - r.dz * e2y;                                   // :69
-        const float pvy = r.dz * e2x - r.dx * e2z;
-        const float pvz = r.dx * e2y - r.dy * e2x;
-        const float det = e1x * pvx + e1y * pvy + e1z * pvz;                         // :70
-        const bool parallel = det < 0.00001f && det > -0.00001f;                     // :73
-        const float inv = reciprocal_ieee(det);                                      // :77
-        const float tvx = r.ox - v0x, tvy = r.oy - v0y, tvz = r.oz - v0z;            // :78
-        const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;                   // :79
-        const bool out_u = u < 0.0f || u > 1.0f;                                     // :80
-        const float qvx = tvy * e1z - tvz * e1y;                                     // :84
-        const float qvy = tvz * e1x - tvx * e1z;
-        const float qvz = tvx * e1y - tvy * e1x;
-        const float v = (r.dx * qvx + r.dy * qvy + r.dz * qvz) * inv;                // :85
-        const bool out_v = v < 0.0f || u + v > 1.0f;                                 // :86
-        const float t = (e2x * qvx + e2y * qvy + e2z * qvz) * inv;                   // :92
-        if (!parallel && !out_u && !out_v && !(t < 1.0f) &&
-            own_box_passes<true>(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2], r) &&
-            candidate_occludes(r, t)) {
-            r.best_t = __uint_as_float(remembered);
-            r.best_idx = tr->idx;
-            r.active = false;
-        }
-    }
-}
-
 template <bool COUNT, bool ANYHIT = false, bool FAST_OK = false, bool VEC = false>
 __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
                                                const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
@@ -690,8 +635,7 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
             if (own_box_passes<FAST_OK>(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2], r)) {
                 const uint32_t idx = tr->idx;
                 if (ANYHIT) {
-                    // (nothing reads an occluder's distance; the slot carries the record's position: test_remembered)
-                    if (candidate_occludes(r, t)) { r.best_t = RTX_REMEMBER_OCCLUDER ? __uint_as_float(first + k) : t; r.best_idx = idx; }
+                    if (candidate_occludes(r, t)) { r.best_t = t; r.best_idx = idx; }
                 } else {
                     bool take = t < r.best_t;
                     if (!take && t == r.best_t && r.best_idx != kNone)   // exact tie: right-most reference leaf wins (bvh.rs:123-130)
@@ -1165,8 +1109,7 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                             LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
-                                            bool first_global_ruled_out = false, uint32_t remembered = kNone,
-                                            uint32_t n_prims = 0u)
+                                            bool first_global_ruled_out = false)
 {
     unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
     // direction classes: six compares voted one by one (direction_is_regular); the hard test runs only when some
@@ -1177,11 +1120,6 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     const bool all_regular = (alive & ~regular) == 0ull;
     if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
     const bool use_fast = FAST && all_regular;
-    if (ANYHIT && RTX_REMEMBER_OCCLUDER && !SPHERES && use_fast && n_prims != 0u) {
-        test_remembered<COUNT>(tris, n_prims, r, remembered, wc);
-        alive = ballot(r.active);
-        if (alive == 0ull) return true;
-    }
     unsigned long long n_active = 0;
     if (COUNT) n_active = __popcll(alive);
     // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
@@ -1199,23 +1137,9 @@ __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__
                                         const TriRec RTX_CONSTANT *__restrict__ tris,
                                         const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                         LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
-                                        bool first_global_ruled_out = false, uint32_t remembered = kNone,
-                                        uint32_t n_prims = 0u)
+                                        bool first_global_ruled_out = false)
 {
-#if RTX_EXPERIMENT_UMBRA      // counted frames only: which walks (by their outcome) the counters see
-    const WaveCounters before = wc;
-    const unsigned long long alive = ballot(r.active);
-    const bool ok = closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out,
-                                                                  remembered, n_prims);
-    const unsigned long long lit = ballot(r.active);
-    const uint32_t outcome = lit == 0ull ? 1u : (lit == alive ? 2u : 3u);       // all occluded / none / some
-    if (outcome != RTX_EXPERIMENT_UMBRA) wc = before;
-    else wc.tri_tests += 1ull << 40;                                            // walks of this kind, in the high bits
-    return ok;
-#else
-    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out,
-                                                         remembered, n_prims);
-#endif
+    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
 }
 
 // ---- the wide walk (A/B builds only: -DRTX_WIDE_WALK=1 / -DRTX_PROBE_WIDE=1; librtx.so walks the binary stream) -------
@@ -1417,40 +1341,21 @@ __device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
                                             uint32_t n_cut, LaneRay &r, WaveCounters &wc, uint32_t n_global,
-                                            bool first_global_ruled_out, uint32_t remembered = kNone,
-                                            uint32_t n_prims = 0u)
+                                            bool first_global_ruled_out)
 {
-    unsigned long long alive = ballot(r.active);
+    const unsigned long long alive = ballot(r.active);
     const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
                                        ballot(fabsf(r.dy) >= 0x1p-60f) & ballot(fabsf(r.dy) <= 2.0f) &
                                        ballot(fabsf(r.dz) >= 0x1p-60f) & ballot(fabsf(r.dz) <= 2.0f);
     const bool all_regular = (alive & ~regular) == 0ull;          // direction classes: see closest_hit
     if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
-#if RTX_EXPERIMENT_UMBRA      // counted frames only: which walks (by their outcome) the counters see
-    const WaveCounters before = wc;
-    const unsigned long long alive_at_entry = alive;
-#endif
-    if (RTX_REMEMBER_OCCLUDER && !SPHERES && FAST && all_regular && n_prims != 0u) {
-        test_remembered<COUNT>(tris, n_prims, r, remembered, wc);
-        alive = ballot(r.active);
-        if (!RTX_EXPERIMENT_UMBRA && alive == 0ull) return true;
-    }
     unsigned long long n_active = 0;
     if (COUNT) n_active = __popcll(alive);
-    if (RTX_EXPERIMENT_UMBRA && alive == 0ull) { /* counted below */ } else
     if (FAST && all_regular)
         walk_cut<COUNT, SPHERES, true, LEAN>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global,
                                              (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
     else
         walk_cut<COUNT, SPHERES, false, false>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global, 0u);
-#if RTX_EXPERIMENT_UMBRA
-    {
-        const unsigned long long lit = ballot(r.active);
-        const uint32_t outcome = lit == 0ull ? 1u : (lit == alive_at_entry ? 2u : 3u);   // all occluded / none / some
-        if (outcome != RTX_EXPERIMENT_UMBRA) wc = before;
-        else wc.tri_tests += 1ull << 40;                                        // walks of this kind, in the high bits
-    }
-#endif
     return true;
 }
 
