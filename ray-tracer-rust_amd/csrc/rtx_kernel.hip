@@ -396,35 +396,6 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #ifndef RTX_PROBE_WAVES
 #define RTX_PROBE_WAVES 1
 #endif
-// 1: a workgroup of probe_kernel is FOUR tiles, one wavefront each, and a primary walk that is not over after
-// RTX_PROBE_LEAF_BUDGET leaves is finished by the four wavefronts together (rtx_traverse.hpp: closest_hit_begin).  The pass
-// is as long as its longest wavefront — a silhouette tile's primary walk, ten times the mean — and that wavefront runs
-// alone on its SIMD at half the issue rate of a shared one.
-#ifndef RTX_PROBE_SHARE
-#define RTX_PROBE_SHARE 1
-#endif
-#ifndef RTX_PROBE_LEAF_BUDGET
-#define RTX_PROBE_LEAF_BUDGET 24
-#endif
-constexpr uint32_t kProbeWaves = (RTX_PROBE_SHARE && !RTX_WIDE_WALK && !RTX_PROBE_WIDE) ? 4u : (uint32_t)RTX_PROBE_WAVES;
-constexpr bool kProbeShare = RTX_PROBE_SHARE && !RTX_WIDE_WALK && !RTX_PROBE_WIDE;
-// Which tiles a workgroup of the shared form takes.  Workgroups b, b + 8, ... share an XCD and its L2; the XCDs are dealt
-// runs of 64 consecutive tile numbers (one 64 x 64 pixel block each: run R belongs to XCD R % 8), as in the one-tile form.
-// A workgroup's four tiles come from four runs of ITS XCD a quarter of the frame apart — a silhouette tile then shares a
-// workgroup with three tiles of the sky or the open ground far more often than with its neighbours.
-__host__ __device__ inline uint32_t probe_share_groups(uint32_t n_tiles)
-{
-    const uint32_t runs_per_xcd = ((n_tiles + 63u) / 64u + 7u) / 8u;
-    return 8u * 64u * ((runs_per_xcd + 3u) / 4u);
-}
-__device__ __forceinline__ uint32_t probe_share_tile(uint32_t group, uint32_t wave, uint32_t n_tiles)
-{
-    const uint32_t runs_per_xcd = ((n_tiles + 63u) / 64u + 7u) / 8u, quarter = (runs_per_xcd + 3u) / 4u;
-    const uint32_t xcd = group & 7u, k = group >> 3;
-    const uint32_t j = wave * quarter + (k >> 6);
-    const uint32_t tile = ((j * 8u + xcd) << 6) + (k & 63u);
-    return (j < runs_per_xcd && tile < n_tiles) ? tile : kNone;
-}
 
 // ---- the cut of a tile ------------------------------------------------------------------------------------------
 // The hundred chunks of a tile send their shadow rays from its hit points to the same few light points: all of them
@@ -654,44 +625,34 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
 }
 
 template <bool COUNT, bool FAST, bool SPHERES>
-__global__ void __launch_bounds__(64 * kProbeWaves) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
+__global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
                                                    uint32_t r, StreamWorkspace W, uint8_t *__restrict__ out,
                                                    uint32_t *__restrict__ queue, unsigned long long *__restrict__ counters)
 {
     const NodeRec RTX_CONSTANT *nodes = (const NodeRec RTX_CONSTANT *)S.nodes;
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
-    // one wavefront per tile, kProbeWaves wavefronts per workgroup (independent of each other except where a long
-    // primary walk is shared: the only barriers; otherwise LDS only inside shaft_cut)
-    __shared__ uint32_t l_front_all[kProbeWaves][128];   // the cut's next frontier: node, subtree size
-    __shared__ uint32_t l_resume[kProbeWaves];           // shared walks: where each wavefront's walk stopped (n_nodes: complete)
-    __shared__ float l_part_t[kProbeWaves][64];          // shared walks: the rays' closest hits, going in (row 0) and coming out
-    __shared__ uint32_t l_part_idx[kProbeWaves][64];
+    // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no barrier; LDS only inside shaft_cut)
+    __shared__ uint32_t l_front_all[RTX_PROBE_WAVES][128];   // the cut's next frontier: node, subtree size
 #if RTX_ABLATION
-    __shared__ __align__(16) uint32_t l_j1_block[kProbeWaves][kJ1BlockWords];   // RTX_J1=2: a block of 64 primitive records
+    __shared__ __align__(16) uint32_t l_j1_block[RTX_PROBE_WAVES][kJ1BlockWords];   // RTX_J1=2: a block of 64 primitive records
 #endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *const l_front = l_front_all[wave_in_group];
-#if RTX_PROBE_SHARE && !RTX_WIDE_WALK && !RTX_PROBE_WIDE
-    const uint32_t tile_id = probe_share_tile(blockIdx.x, wave_in_group, n_tiles);
-    const bool has_tile = tile_id != kNone;            // (a wavefront without a tile still helps with the others' walks)
-#elif RTX_PROBE_XCD
+#if RTX_PROBE_XCD
     // workgroups b, b + 8, ... share an XCD (MI355X_MICROARCH.md, workgroup dispatch): the XCDs are dealt runs of 64
     // consecutive tile numbers — one 64 x 64 pixel block each — so that an L2 serves neighbouring tiles' walks.  (One
     // contiguous eighth of the frame per XCD was 25-35 % slower: the upper half of a frame is sky.)
     static_assert(RTX_PROBE_WAVES == 1, "the XCD mapping assumes one tile per workgroup");
     const uint32_t k = blockIdx.x >> 3;
     const uint32_t tile_id = ((((k >> 6) << 3) + (blockIdx.x & 7u)) << 6) + (k & 63u);
-    if (tile_id >= n_tiles) return;
-    const bool has_tile = true;
 #else
     const uint32_t tile_id = blockIdx.x * RTX_PROBE_WAVES + wave_in_group;
-    if (tile_id >= n_tiles) return;
-    const bool has_tile = true;
 #endif
-    uint32_t px = 0u, py = 0u, ly = 0u, tile_x, tile_y;
-    tile_xy(has_tile ? tile_id : 0u, tiles_x, RTX_TILE_BLOCKS != 0, tile_x, tile_y);
-    const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly) && has_tile;
+    if (tile_id >= n_tiles) return;
+    uint32_t px, py, ly, tile_x, tile_y;
+    tile_xy(tile_id, tiles_x, RTX_TILE_BLOCKS != 0, tile_x, tile_y);
+    const bool in_frame = tile_pixel(S, ts, tile_x, tile_y, lane, px, py, ly);
     WaveCounters wc;
     float dx, dy, dz;
     primary_ray(S, in_frame, px, py, r, dx, dy, dz);
@@ -706,60 +667,12 @@ __global__ void __launch_bounds__(64 * kProbeWaves) probe_kernel(DeviceScene S, 
     const bool ok = hit_wide<COUNT, FAST, SPHERES, false>((const WideNode RTX_CONSTANT *)S.wide, S.n_wide, tris, S.shade, nullptr, 0u, pr, wc,
                                                           S.n_global, false);                                  // main.rs:187
     (void)nodes;
+#elif RTX_ABLATION
+    const bool ok = (S.j1_mode == 2u || S.j1_mode == 3u)
+        ? j1_closest_hit_blocks<COUNT>(S.j1_mode, S.tris, S.shade, S.n_prims, pr, wc, lane, l_j1_block[wave_in_group])
+        : closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);               // main.rs:187
 #else
-    // main.rs:187 — a walk that is not over after its budget of leaves is finished by the workgroup's wavefronts together
-    uint32_t resume = S.n_nodes;
-    bool ok;
-#if RTX_ABLATION
-    if (S.j1_mode == 2u || S.j1_mode == 3u)
-        ok = !has_tile || j1_closest_hit_blocks<COUNT>(S.j1_mode, S.tris, S.shade, S.n_prims, pr, wc, lane, l_j1_block[wave_in_group]);
-    else
-#endif
-    if (kProbeShare)
-        ok = !has_tile || closest_hit_begin<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global,
-                                                                  RTX_PROBE_LEAF_BUDGET, resume);
-    else
-        ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);
-#if RTX_PROBE_SHARE
-    if (lane == 0) l_resume[wave_in_group] = resume;
-    __syncthreads();
-    for (uint32_t k = 0; k < kProbeWaves; ++k) {
-        const uint32_t from = __builtin_amdgcn_readfirstlane(l_resume[k]);   // (the same in every wavefront: the barriers below are met by all)
-        if (from >= S.n_nodes) continue;
-        if (wave_in_group == k) { l_part_t[0][lane] = pr.best_t; l_part_idx[0][lane] = pr.best_idx; }
-        __syncthreads();
-        // wavefront k's rays, with what they have found so far (to prune by)
-        const uint32_t tile_k = probe_share_tile(blockIdx.x, k, n_tiles);
-        uint32_t qx = 0u, qy = 0u, qly = 0u, tkx, tky;
-        tile_xy(tile_k, tiles_x, RTX_TILE_BLOCKS != 0, tkx, tky);
-        const bool q_in = tile_pixel(S, ts, tkx, tky, lane, qx, qy, qly);
-        float qdx, qdy, qdz;
-        primary_ray(S, q_in, qx, qy, r, qdx, qdy, qdz);
-        LaneRay q = make_ray(q_in, S.eye[0], S.eye[1], S.eye[2], qdx, qdy, qdz);
-        q.best_t = l_part_t[0][lane];
-        q.best_idx = l_part_idx[0][lane];
-        __syncthreads();                                           // (row 0 is read: it is this wavefront 0's result row next)
-        const uint32_t left = S.n_nodes - from;
-        const uint32_t a = from + (uint32_t)(((unsigned long long)left * wave_in_group) / kProbeWaves);
-        const uint32_t b = from + (uint32_t)(((unsigned long long)left * (wave_in_group + 1u)) / kProbeWaves);
-        walk_piece<COUNT, SPHERES>(nodes, tris, S.shade, a, b, q, wc);
-        l_part_t[wave_in_group][lane] = q.best_t;
-        l_part_idx[wave_in_group][lane] = q.best_idx;
-        __syncthreads();
-        if (wave_in_group == k) {
-            for (uint32_t w = 0; w < kProbeWaves; ++w)
-                merge_closest(S.shade, pr.best_t, pr.best_idx, l_part_t[w][lane], l_part_idx[w][lane]);
-        }
-        __syncthreads();
-    }
-    if (!has_tile) {
-        if (COUNT && lane == 0) {
-            flush_counters<COUNT>(counters, 0ull, wc);
-            if (counters) { atomicAdd(&counters[6], wc.node_visits); atomicAdd(&counters[7], wc.tri_visits); }
-        }
-        return;
-    }
-#endif
+    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
 #endif
 #if RTX_EXPERIMENT_PROBE_PHASES
     const unsigned long long pp_t1 = wall_clock64();
@@ -1560,9 +1473,8 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
         if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(W.buckets, 0, 3u * kCostBuckets * sizeof(uint32_t), stream)) != hipSuccess) return e;
         hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>),
-                           dim3(kProbeShare ? probe_share_groups(n_tiles)
-                                            : RTX_PROBE_XCD ? 512u * ((n_tiles + 511u) / 512u) : (n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
-                           dim3(64 * kProbeWaves), 0, stream, S, ts, tiles_x, n_tiles,
+                           dim3(RTX_PROBE_XCD ? 512u * ((n_tiles + 511u) / 512u) : (n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
+                           dim3(64 * RTX_PROBE_WAVES), 0, stream, S, ts, tiles_x, n_tiles,
                            r, W, d_out, d_redo, d_counters);
         hipLaunchKernelGGL(count_classes_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W);
         hipLaunchKernelGGL(order_tiles_kernel, dim3((n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, n_tiles, W, grid, split_share());
@@ -1680,7 +1592,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
-    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_LEAF_BUDGET) RTX_SW(RTX_PROBE_SHARE) RTX_SW(RTX_PROBE_WAVES)
+    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD)
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
     RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)

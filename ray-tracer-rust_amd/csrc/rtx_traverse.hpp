@@ -1130,90 +1130,6 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     return true;
 }
 
-// ---- a closest-hit walk that can be handed on (probe_kernel) ------------------------------------------------------------
-// A primary walk is one wavefront's chain of dependent steps; a silhouette tile's is ten times the mean, and the longest of
-// them is the length of the scheduling pass.  closest_hit_begin walks like closest_hit but stops after `leaves` visited
-// leaves: `resume` is then the record at which the walk goes on (n_nodes: the walk is complete).  What is left, the
-// records [resume, n_nodes), is a range ANY split of which can be walked by different wavefronts with the same rays
-// (walk_piece): a range may begin at any record — culling only has to keep a superset, and a record tested without its
-// ancestors' tests is still tested — every record lies in exactly one piece, and the closest hit of the whole is the
-// minimum of the pieces' under the leaf rule's own order (closer; on an exact tie the higher rank: merge_closest).
-// Only the multiply-based walk is handed on; a wavefront holding a soft direction walks alone, to the end.
-template <bool COUNT, bool FAST, bool SPHERES>
-__device__ __forceinline__ bool closest_hit_begin(const NodeRec RTX_CONSTANT *__restrict__ nodes,
-                                                  const TriRec RTX_CONSTANT *__restrict__ tris,
-                                                  const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
-                                                  WaveCounters &wc, uint32_t n_global, uint32_t leaves, uint32_t &resume)
-{
-    resume = n_nodes;
-    const unsigned long long alive = ballot(r.active);
-    const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
-                                       ballot(fabsf(r.dy) >= 0x1p-60f) & ballot(fabsf(r.dy) <= 2.0f) &
-                                       ballot(fabsf(r.dz) >= 0x1p-60f) & ballot(fabsf(r.dz) <= 2.0f);
-    const bool all_regular = (alive & ~regular) == 0ull;          // direction classes: see closest_hit
-    if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
-    unsigned long long n_active = 0;
-    if (COUNT) n_active = __popcll(alive);
-#if RTX_ASM_WALK && RTX_CULL_FMA && RTX_CULL_INFLATED && !RTX_CULL_PACKED && RTX_SKIP_ROOT_TEST
-    if (FAST && all_regular) {
-        uint32_t i = n_nodes > 1u ? 1u : 0u;                      // walk_stream: the root's own test is skipped, ...
-        if (n_global != 0u) {                                     // ... the global triangles are tested without their box
-            leaf_triangles<COUNT, false, true>(tris, shade, 0u, n_global, r, alive, n_active, wc);
-            i = 2u;
-        }
-        uint32_t off = __builtin_amdgcn_readfirstlane(i << 5);
-        const uint32_t end_off = __builtin_amdgcn_readfirstlane(n_nodes << 5);
-        const uint32_t oct = walk_octant(r, alive);
-        while (off < end_off) {
-            uint32_t link, info, visits = 0u;
-            advance_to_leaf<COUNT, RTX_PRUNE_CLOSEST != 0>(nodes, off, end_off, alive, r, oct, link, info, visits,
-                                                           r.best_t * (1.0f + 0x1p-16f));
-            if (COUNT) { wc.box_tests += n_active * visits; wc.node_visits += visits; }
-            if (info == 0u) return true;
-            if (SPHERES && (info & kSphereFlag))
-                leaf_spheres<COUNT, false>(tris, shade, info & kLeafIndexMask, link, r, n_active, wc);
-            else
-                leaf_triangles<COUNT, false, true>(tris, shade, info & kLeafIndexMask, link, r, alive, n_active, wc);
-            off += 32u;
-            if (--leaves == 0u) {
-                if (off < end_off) resume = off >> 5;
-                return true;
-            }
-        }
-        return true;
-    }
-#endif
-    (void)leaves;
-    if (FAST && all_regular)
-        walk_stream<COUNT, SPHERES, false, true>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global, 0u);
-    else
-        walk_stream<COUNT, SPHERES, false, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
-    return true;
-}
-
-// the records [begin, end) of a walk that closest_hit_begin has handed on (regular directions: the multiply-based test)
-template <bool COUNT, bool SPHERES>
-__device__ __forceinline__ void walk_piece(const NodeRec RTX_CONSTANT *__restrict__ nodes,
-                                           const TriRec RTX_CONSTANT *__restrict__ tris,
-                                           const ShadeRec *__restrict__ shade, uint32_t begin, uint32_t end, LaneRay &r,
-                                           WaveCounters &wc)
-{
-    const unsigned long long alive = ballot(r.active);
-    unsigned long long n_active = 0;
-    if (COUNT) n_active = __popcll(alive);
-    if (begin < end) (void)walk_range<COUNT, SPHERES, false, true>(nodes, tris, shade, begin, end, r, alive, n_active, wc);
-}
-
-// the leaf rule's order between two results of the same ray: closer wins; exact tie: the higher rank (bvh.rs:123-130)
-__device__ __forceinline__ void merge_closest(const ShadeRec *__restrict__ shade, float &best_t, uint32_t &best_idx,
-                                              float t, uint32_t idx)
-{
-    bool take = t < best_t;
-    if (!take && t == best_t && idx != best_idx && idx != kNone && best_idx != kNone)
-        take = shade[idx].rank > shade[best_idx].rank;
-    if (take) { best_t = t; best_idx = idx; }
-}
-
 // any_hit: the walk of a shadow ray.  r.limit = distance to the light point; on return r.best_idx != kNone iff the
 // sample is occluded (see candidate_occludes), r.active is consumed.
 template <bool COUNT, bool FAST, bool SPHERES = false, bool LEAN = false>
