@@ -396,6 +396,14 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #ifndef RTX_PROBE_WAVES
 #define RTX_PROBE_WAVES 1
 #endif
+// 1: the probing walk of a tile of a scene without cuts (probe_kernel: the tile's hit pixels towards light sample 0, for the
+// cost estimate) is the shading pass's chunk 0 where the tile is full and numbered sample-major; its answers are kept.
+#ifndef RTX_WHOLE_DRAW_CHUNKS
+#define RTX_WHOLE_DRAW_CHUNKS 1
+#endif
+#ifndef RTX_KEEP_PROBING_WALK
+#define RTX_KEEP_PROBING_WALK 1
+#endif
 
 // ---- the cut of a tile ------------------------------------------------------------------------------------------
 // The hundred chunks of a tile send their shadow rays from its hit points to the same few light points: all of them
@@ -748,13 +756,26 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
             // 1M-triangle soup: 61 ms with this estimate, 65-67 ms with the cut's proxy at any cut size.)
             n_cut = 0u;   // (shade_tiles_kernel's whole-stream form does not read a cut)
             const float *lp = S.light_points + 3u * (r * S.nb_light);
-            const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;
-            const float dist_light = sqrtf(vx * vx + vy * vy + vz * vz);
-            LaneRay sr = make_ray(hit, hx, hy, hz, vx / dist_light, vy / dist_light, vz / dist_light);
+            const float vx = lp[0] - hx, vy = lp[1] - hy, vz = lp[2] - hz;              // main.rs:201-202, as shadow_ray_at
+            float dist_light, sx, sy, sz;
+            (void)length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);
+            LaneRay sr = make_ray(hit, hx, hy, hz, sx, sy, sz);
             sr.limit = dist_light;
             WaveCounters probe;
-            (void)any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
+            const bool walked = any_hit<true, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, sr, probe, S.n_global);
             weight = (uint32_t)(probe.node_visits + probe.tri_visits);
+            // In a FULL tile numbered sample-major these 64 rays ARE the shading pass's chunk 0 — hit pixel `lane` towards
+            // light sample 0, the same origin, light point and normalisation — so their answers are kept (two words where
+            // a cut would lie) and shade_tiles_kernel does not walk that chunk again: one walk in a hundred.
+            if (RTX_KEEP_PROBING_WALK && walked && n_hit == 64u && (flags & 1u)) {
+                const unsigned long long occluded = ballot(sr.best_idx != kNone);
+                if (lane == 0) {
+                    uint32_t *kept = reinterpret_cast<uint32_t *>(W.cut + (size_t)tile_id * kMaxCut);
+                    kept[0] = (uint32_t)occluded;
+                    kept[1] = (uint32_t)(occluded >> 32);
+                }
+                flags |= kTileChunk0Kept;
+            }
         }
 #endif
         cost = (unsigned long long)(kChunkFixedCost + weight) * n_chunks;
@@ -1115,6 +1136,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         const bool sample_major = (tflags & 1u) != 0u;
         const bool skip = (tflags & 2u) != 0u;      // already queued for the reference re-render
         const uint32_t n_cut = (tflags >> kTileCutShift) & 0xFFu;
+        // whole-stream form: chunk 0 of a full sample-major tile was walked by probe_kernel (its probing walk); the answers
+        // lie where a cut would (words 0 and 1: work-items 0 and 1 of wavefront 0, which is the wavefront that has chunk 0)
+        const bool chunk0_kept = WHOLE && RTX_KEEP_PROBING_WALK != 0 && (tflags & kTileChunk0Kept) != 0u && parts_log == 0u &&
+                                 n_hit == 64u && sample_major;
+        const uint32_t kept_lo = __builtin_amdgcn_readlane(cut_word, 0), kept_hi = __builtin_amdgcn_readlane(cut_word, 1);
         if (!skip) {
             if (parts_log == 0u) {
 #pragma unroll
@@ -1172,6 +1198,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         for (uint32_t k = threadIdx.x; k < 3u * bc; k += 64u * NW)
                             l_light[k] = S.light_points[3u * (r * S.nb_light + b0) + k]; // main.rs:194-196 (hoisted to the host)
                     }
+                    if (WHOLE && RTX_WHOLE_DRAW_CHUNKS != 0 && threadIdx.x == 0) l_ctl[0] = 0u;   // chunks drawn so far (behind the first NW)
                     __syncthreads();   // (also publishes the grey flag)
                     // A tile with an empty cut is through its rays in 10 us: the next job's position in the list is requested
                     // now, by the work-item that claims the jobs, and turned into a job id when the ordered sums start —
@@ -1246,7 +1273,12 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
                     }
 #endif
-                    for (uint32_t c0 = c_first; c0 < total; c0 += 64u * NW) {
+                    // Whole-stream form: a wavefront DRAWS its next chunk (a counter in LDS) instead of being dealt every NW-th.
+                    // Its chunks are walks of the whole stream whose lengths differ by an order of magnitude (a chunk in the
+                    // open: a dozen records; one whose rays all end in the mesh: two hundred), and a job ends when its slowest
+                    // wavefront does.  (The cut form's chunks are short and alike: drawn there, +1 ... +4 %, profiles/r02.)
+                    constexpr bool kDrawChunks = WHOLE && RTX_WHOLE_DRAW_CHUNKS != 0;
+                    for (uint32_t c0 = c_first; c0 < total; ) {
                         ShadowRay sr;
                         if (RTX_FULL_TILE_GENERAL && full_tile) {   // chunk = light sample c0 / 64 of the tile's 64 pixels
                             sr = shadow_ray_from(my_hit, l_light, true, lane, c0 >> 6);
@@ -1269,7 +1301,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         ok = hit_wide<COUNT, FAST, SPHERES, true>(wide, S.n_wide, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground);   // main.rs:204
 #else
                         const bool nothing_to_walk = n_cut == 0u && !whole_tree && (S.n_global == 0u || (S.n_global == 1u && no_ground));
-                        if (nothing_to_walk) {
+                        if (WHOLE && chunk0_kept && c0 == 0u && b0 == 0u) {   // probe_kernel has walked these rays: its answers
+                            const unsigned long long occluded = ((unsigned long long)kept_hi << 32) | kept_lo;
+                            sr.ray.best_idx = ((occluded >> lane) & 1ull) ? 0u : kNone;
+                            ok = true;
+                        } else if (nothing_to_walk) {
                             ok = sr.not_hard || ballot(sr.ray.active && direction_is_hard(sr.ray.dx, sr.ray.dy, sr.ray.dz)) == 0ull;
                         } else {
                             ray_cull_constants(sr.ray);                              // main.rs:204
@@ -1292,6 +1328,13 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         if (RTX_FULL_TILE_GENERAL && grey_tile && full_tile) shadow_result_grey_from(my_hit, l_res, res_stride, sr, denom_d);
                         else if (grey_tile) shadow_result_grey<!WHOLE>(l_hit, l_res, res_stride, sr, denom_d);   // (whole-stream form: no registers to spare, +0.7 %)
                         else shadow_result(l_hit, l_res, res_stride, sr);
+                        if (kDrawChunks) {
+                            uint32_t drawn = 0u;
+                            if (lane == 0) drawn = atomicAdd(&l_ctl[0], 1u);
+                            c0 = (NW + __builtin_amdgcn_readfirstlane(drawn)) * 64u;
+                        } else {
+                            c0 += 64u * NW;
+                        }
                     }
 #if RTX_SHADE_PRIORITY
                     __builtin_amdgcn_s_setprio(RTX_SHADE_PRIORITY);
@@ -1592,8 +1635,8 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
-    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
-    RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD)
+    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
+    RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD) RTX_SW(RTX_WHOLE_DRAW_CHUNKS)
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
     RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)
     RTX_SW(RTX_TILE_BLOCKS) RTX_SW(RTX_TILE_PARTS_MAX) RTX_SW(RTX_TRIANGLE_EARLY_OUT)
