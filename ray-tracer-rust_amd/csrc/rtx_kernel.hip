@@ -398,6 +398,13 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #endif
 // 1: the probing walk of a tile of a scene without cuts (probe_kernel: the tile's hit pixels towards light sample 0, for the
 // cost estimate) is the shading pass's chunk 0 where the tile is full and numbered sample-major; its answers are kept.
+// Cut form: a tile whose cut has at least this many entries — a tile that walks — draws its chunks as well (0: none do).
+// Round 2 measured this a loss (+1 % on big_bunny 1080p: the walks were slower then and the jobs that never draw paid for
+// the loop's shape); with the hand-written box step it is -2.3 % there (six interleaved rounds) and -0.5 % at 4096x4096;
+// from 8 entries on: -2.1 % / -0.3 % (profiles/r03/x4_*).
+#ifndef RTX_CUT_DRAW_MIN
+#define RTX_CUT_DRAW_MIN 1
+#endif
 #ifndef RTX_WHOLE_DRAW_CHUNKS
 #define RTX_WHOLE_DRAW_CHUNKS 1
 #endif
@@ -1198,7 +1205,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         for (uint32_t k = threadIdx.x; k < 3u * bc; k += 64u * NW)
                             l_light[k] = S.light_points[3u * (r * S.nb_light + b0) + k]; // main.rs:194-196 (hoisted to the host)
                     }
-                    if (WHOLE && RTX_WHOLE_DRAW_CHUNKS != 0 && threadIdx.x == 0) l_ctl[0] = 0u;   // chunks drawn so far (behind the first NW)
+                    if (((WHOLE && RTX_WHOLE_DRAW_CHUNKS != 0) || RTX_CUT_DRAW_MIN != 0) && threadIdx.x == 0) l_ctl[0] = 0u;   // chunks drawn so far (behind the first NW)
                     __syncthreads();   // (also publishes the grey flag)
                     // A tile with an empty cut is through its rays in 10 us: the next job's position in the list is requested
                     // now, by the work-item that claims the jobs, and turned into a job id when the ordered sums start —
@@ -1273,11 +1280,12 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                         }
                     }
 #endif
-                    // Whole-stream form: a wavefront DRAWS its next chunk (a counter in LDS) instead of being dealt every NW-th.
-                    // Its chunks are walks of the whole stream whose lengths differ by an order of magnitude (a chunk in the
-                    // open: a dozen records; one whose rays all end in the mesh: two hundred), and a job ends when its slowest
-                    // wavefront does.  (The cut form's chunks are short and alike: drawn there, +1 ... +4 %, profiles/r02.)
-                    constexpr bool kDrawChunks = WHOLE && RTX_WHOLE_DRAW_CHUNKS != 0;
+                    // A wavefront DRAWS its next chunk (a counter in LDS) instead of being dealt every NW-th, in the whole-stream
+                    // form and in tiles of the cut form that walk.  Walks differ in length by an order of magnitude (a chunk in
+                    // the open: a dozen records; one whose rays all end in the mesh: fifty to two hundred — the split by outcome
+                    // in DESIGN.md section 4), and a job ends when its slowest wavefront does: the 1M-triangle soup -7 %.
+                    constexpr bool kDrawWhole = WHOLE && RTX_WHOLE_DRAW_CHUNKS != 0;
+                    const bool kDrawChunks = kDrawWhole || (RTX_CUT_DRAW_MIN != 0 && n_cut >= RTX_CUT_DRAW_MIN);
                     for (uint32_t c0 = c_first; c0 < total; ) {
                         ShadowRay sr;
                         if (RTX_FULL_TILE_GENERAL && full_tile) {   // chunk = light sample c0 / 64 of the tile's 64 pixels
@@ -1632,7 +1640,7 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
-    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
+    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
