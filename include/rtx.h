@@ -220,6 +220,10 @@ int rtx_scene_gamma_thresholds(const RtxScene *scene, float *out256);
 int rtx_scene_normals(const RtxScene *scene, float *out);
 /* the traversal stream: node records (8 dwords each) and the triangle order of the leaves */
 int rtx_scene_nodes(const RtxScene *scene, uint32_t *out_dwords /* n_nodes*8 */, uint32_t *out_tri_order /* n_tris */);
+/* the stream the PRIMARY rays walk: the same tree and the same n_nodes records as rtx_scene_nodes, of every node's children
+   the one nearer the eye first (the shadow rays' stream puts the one farther from the light first); *out_own = 1 when the
+   scene has such a stream of its own, 0 when the primary rays walk rtx_scene_nodes' stream (which is then what is copied) */
+int rtx_scene_primary_nodes(const RtxScene *scene, uint32_t *out_dwords /* n_nodes*8 */, uint32_t *out_own);
 /* the reference-tree stream (n_ref_nodes*8 dwords; leaf info = 0x80000000 | position in out_tri_order) */
 int rtx_scene_ref_nodes(const RtxScene *scene, uint32_t *out_dwords);
 

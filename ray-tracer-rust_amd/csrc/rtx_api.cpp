@@ -36,7 +36,7 @@ thread_local int g_last_hip_error = 0;
 struct DeviceState {
     std::mutex mu;
     bool uploaded = false;
-    void *nodes = nullptr, *wide = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr, *light_boxes = nullptr;
+    void *nodes = nullptr, *primary_nodes = nullptr, *wide = nullptr, *ref_nodes = nullptr, *tris = nullptr, *shade = nullptr, *samples = nullptr, *lights = nullptr, *thr = nullptr, *planes = nullptr, *light_boxes = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_out = nullptr;
@@ -132,6 +132,8 @@ int upload_all(RtxScene *scene, DeviceState &st)
     int rc;
     const float inflate = RTX_CULL_INFLATED ? p.cull_delta : 0.0f;
     if ((rc = upload_vec(&st.nodes, rtx::nodes_in_device_order(p.nodes, inflate), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
+    if (!p.primary_nodes.empty() &&
+        (rc = upload_vec(&st.primary_nodes, rtx::nodes_in_device_order(p.primary_nodes, inflate), sizeof(rtx::NodeRec))) != RTX_OK) return rc;
     if (!p.wide.empty()) {   // A/B builds only (scene_prep.h: kBuildWideTree); boxes moved outwards like the binary stream's
         std::vector<rtx::WideNode> w = p.wide;
         for (rtx::WideNode &n : w)
@@ -163,7 +165,7 @@ int upload_all(RtxScene *scene, DeviceState &st)
 // what upload_all allocated so far goes back when it fails half way (the caller may retry: nothing may leak)
 void release_uploads(DeviceState &st)
 {
-    void **bufs[] = {&st.nodes, &st.wide, &st.ref_nodes, &st.tris, &st.shade, &st.samples, &st.lights, &st.thr, &st.planes, &st.light_boxes,
+    void **bufs[] = {&st.nodes, &st.primary_nodes, &st.wide, &st.ref_nodes, &st.tris, &st.shade, &st.samples, &st.lights, &st.thr, &st.planes, &st.light_boxes,
                      reinterpret_cast<void **>(&st.d_counters)};
     for (void **b : bufs) {
         if (*b) (void)hipFree(*b);
@@ -191,6 +193,7 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     const rtx::PreparedScene &p = scene->prep;
     rtx::DeviceScene S;
     S.nodes = static_cast<const rtx::NodeRec *>(st.nodes);
+    S.primary_nodes = static_cast<const rtx::NodeRec *>(st.primary_nodes ? st.primary_nodes : st.nodes);
     S.wide = static_cast<const rtx::WideNode *>(st.wide);
     S.n_wide = static_cast<uint32_t>(p.wide.size());
     S.ref_nodes = static_cast<const rtx::NodeRec *>(st.ref_nodes);
@@ -394,7 +397,7 @@ void rtx_scene_destroy(RtxScene *scene)
         DeviceGuard g(kv.first);
         if (g.status() != hipSuccess) continue;
         if (st.stream) (void)hipStreamSynchronize(st.stream);
-        void *bufs[] = {st.nodes, st.wide, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.light_boxes, st.d_out, st.d_counters, st.d_redo,
+        void *bufs[] = {st.nodes, st.primary_nodes, st.wide, st.ref_nodes, st.tris, st.shade, st.samples, st.lights, st.thr, st.planes, st.light_boxes, st.d_out, st.d_counters, st.d_redo,
                         st.ws.hits, st.ws.pix_slot, st.ws.tiles, st.ws.chunks, st.ws.results, st.ws.acc, st.ws.ctr, st.ws.buckets, st.ws.cut};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (st.h_stage) (void)hipHostFree(st.h_stage);
@@ -724,6 +727,16 @@ int rtx_scene_ref_nodes(const RtxScene *scene, uint32_t *out_dwords)
 {
     if (!scene || !out_dwords) return RTX_ERR_BAD_ARG;
     std::memcpy(out_dwords, scene->prep.ref_nodes.data(), scene->prep.ref_nodes.size() * sizeof(rtx::NodeRec));
+    return RTX_OK;
+}
+
+int rtx_scene_primary_nodes(const RtxScene *scene, uint32_t *out_dwords, uint32_t *out_own)
+{
+    if (!scene) return RTX_ERR_BAD_ARG;
+    const bool own = !scene->prep.primary_nodes.empty();
+    const std::vector<rtx::NodeRec> &v = own ? scene->prep.primary_nodes : scene->prep.nodes;
+    if (out_dwords) std::memcpy(out_dwords, v.data(), v.size() * sizeof(rtx::NodeRec));
+    if (out_own) *out_own = own ? 1u : 0u;
     return RTX_OK;
 }
 

@@ -19,6 +19,7 @@ namespace rtx {
 // Passed by value (kernarg segment -> SGPRs).
 struct DeviceScene {
     const NodeRec  *nodes;         // (n_nodes + 1) x 32 B, pre-order with skip links; last = zeroed sentinel
+    const NodeRec  *primary_nodes; // the same tree, the same size, nearest-to-the-eye child first: the primary rays' stream (= nodes when there is none)
     const WideNode *wide;          // A/B builds only (scene_prep.h: kBuildWideTree), else NULL: n_wide x 128 B, the tree with four children per node
     const NodeRec  *ref_nodes;     // (n_ref_nodes + 1) x 32 B: the reference's own tree, or NULL
     const TriRec   *tris;          // n_tris x 64 B, leaf order

@@ -685,9 +685,10 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 #elif RTX_ABLATION
     const bool ok = (S.j1_mode == 2u || S.j1_mode == 3u)
         ? j1_closest_hit_blocks<COUNT>(S.j1_mode, S.tris, S.shade, S.n_prims, pr, wc, lane, l_j1_block[wave_in_group])
-        : closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);               // main.rs:187
+        : closest_hit<COUNT, FAST, SPHERES>((const NodeRec RTX_CONSTANT *)S.primary_nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
 #else
-    const bool ok = closest_hit<COUNT, FAST, SPHERES>(nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
+    // (the primary rays' own stream of the tree, nearest-to-the-eye child first: scene_prep.h, PreparedScene::primary_nodes)
+    const bool ok = closest_hit<COUNT, FAST, SPHERES>((const NodeRec RTX_CONSTANT *)S.primary_nodes, tris, S.shade, S.n_nodes, pr, wc, S.n_global);   // main.rs:187
 #endif
 #if RTX_EXPERIMENT_PROBE_PHASES
     const unsigned long long pp_t1 = wall_clock64();
@@ -1643,7 +1644,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
-    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PROBE_WAVES)
+    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_WAVES)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD) RTX_SW(RTX_WHOLE_DRAW_CHUNKS)
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
     RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)

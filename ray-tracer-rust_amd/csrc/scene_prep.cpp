@@ -138,6 +138,47 @@ int build_gamma_thresholds(float thr[256])
 //     -0.0 component makes an ancestor's slab test reject through +-inf while a flat leaf accepts
 //     through ignored NaNs), so those rays are traced against THIS tree -> out_stream: pre-order,
 //     skip-linked NodeRecs, one triangle per leaf, leaf info = kLeafFlag | caller index.
+void stream_nearest_first(const std::vector<NodeRec> &nodes, uint32_t root, const float *point, std::vector<NodeRec> &out)
+{
+    out.clear();
+    out.reserve(nodes.size());
+    for (uint32_t i = 0; i < root && i < nodes.size(); ++i) out.push_back(nodes[i]);
+    if (root >= nodes.size()) return;
+    auto dist2 = [&](const NodeRec &n) {
+        double d2 = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double c = 0.5 * double(n.bmin[k]) + 0.5 * double(n.bmax[k]) - double(point[k]);
+            d2 += c * c;
+        }
+        return d2;
+    };
+    struct Item { uint32_t node; uint32_t close; };       // close != kNone: the subtree of out[close] ends here
+    constexpr uint32_t none = 0xFFFFFFFFu;
+    std::vector<Item> todo;
+    todo.push_back({root, none});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.close != none) { out[it.close].link = static_cast<uint32_t>(out.size()); continue; }
+        const NodeRec &n = nodes[it.node];
+        const uint32_t pos = static_cast<uint32_t>(out.size());
+        out.push_back(n);
+        if (n.info & kLeafFlag) continue;
+        const uint32_t a = it.node + 1u, b = n.info;      // first child: the next record; second: named by info
+        const bool a_first = !(dist2(nodes[b]) < dist2(nodes[a]));
+        todo.push_back({0u, pos});
+        todo.push_back({a_first ? b : a, none});
+        todo.push_back({a_first ? a : b, none});
+    }
+    // a root in front of the tree proper (the global triangles' leaf beside it) spans the whole stream
+    if (root != 0u && !(out[0].info & kLeafFlag)) out[0].link = static_cast<uint32_t>(out.size());
+    for (size_t i = root; i < out.size(); ++i)             // inner nodes name their second child, as in `nodes`
+        if (!(out[i].info & kLeafFlag)) {
+            const NodeRec &first = out[i + 1];
+            out[i].info = (first.info & kLeafFlag) ? static_cast<uint32_t>(i) + 2u : first.link;
+        }
+}
+
 int ref_tree_build(uint32_t n, const float *v0v1v2, uint32_t *out_rank, std::vector<NodeRec> *out_stream)
 {
     if (!n || !v0v1v2) return RTX_ERR_BAD_ARG;
@@ -723,6 +764,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             s.wide_depth = wide_nodes_build(s.nodes, proper, order_boxes.data(), s.wide);
         };
         s.nodes.clear();
+        s.primary_nodes.clear();
         s.nodes.reserve(2 * static_cast<size_t>(n_prims));
         if (d.accel == RTX_ACCEL_BRUTE) {
             // one leaf per arm (a leaf holds one arm only), under a root when both are present
@@ -844,6 +886,9 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
             };
             build_tree(64u);
             finish_tree();
+            s.primary_nodes.clear();
+            if (RTX_PRIMARY_STREAM && s.n_global < n_prims)
+                stream_nearest_first(s.nodes, s.n_global != 0u ? 2u : 0u, d.eye, s.primary_nodes);
             if (kBuildWideTree && s.wide_depth > kMaxWideDepth) {
                 // the walk's stack holds 3 pending children per wide level: a tree that deep (a pathological scene) is
                 // rebuilt balanced, which halves its levels when the children are pulled up
@@ -851,6 +896,7 @@ int prepare_scene(const RtxSceneDesc &d, PreparedScene &s)
                 while ((1ull << halvings) < n_prims) ++halvings;
                 build_tree(halvings + 3u);
                 finish_tree();
+                s.primary_nodes.clear();      // (A/B builds: the wide walk has no second stream)
                 if (s.wide_depth > kMaxWideDepth) return RTX_ERR_INTERNAL;
             }
         }

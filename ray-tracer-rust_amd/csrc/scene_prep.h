@@ -110,6 +110,10 @@ struct ShadeRec {
 #ifndef RTX_LIGHTWARD_ORDER
 #define RTX_LIGHTWARD_ORDER 1
 #endif
+// 1: a second stream of the same tree for the primary rays, nearest-to-the-eye child first (PreparedScene::primary_nodes)
+#ifndef RTX_PRIMARY_STREAM
+#define RTX_PRIMARY_STREAM 1
+#endif
 static_assert(sizeof(ShadeRec) == 32, "ShadeRec must be 32 bytes");
 
 struct PreparedScene {
@@ -121,6 +125,11 @@ struct PreparedScene {
     uint32_t n_spheres = 0;            // of which spheres
     uint32_t n_samples = 0;
     std::vector<NodeRec>  nodes;
+    // The same tree as a second stream for the PRIMARY rays (probe_kernel), of every node's two children the one whose box
+    // centre lies nearer the EYE first: a closest-hit walk prunes by the closest hit so far, and finds a close one early
+    // this way; `nodes` puts the child farther from the LIGHT first, which is what the shadow walks want.  Same records,
+    // same leaves (a leaf names its run of the primitive array), other order and links.  Empty: `nodes` serves both.
+    std::vector<NodeRec>  primary_nodes;
     std::vector<WideNode> wide;        // A/B builds only (kBuildWideTree): the same tree with four children per node (may be
                                        // empty: a scene of global triangles only); wide[0] is the root.  Else empty.
     uint32_t wide_depth = 0;           // levels of wide nodes
@@ -154,6 +163,9 @@ int prepare_scene(const RtxSceneDesc &desc, PreparedScene &out);
 // Four-child nodes from the binary stream `nodes` (pre-order, inner.info = second child) below record `root`; returns
 // the number of wide levels.  A root that is a leaf gives one wide node with one child.
 // prim_boxes: n x {lo xyz, hi xyz} of the primitive records in leaf order (to bound the runs of a large leaf).
+// `nodes` (pre-order, inner.info = second child) with the children of every inner node below record `root` in the order
+// that puts the one nearer to `point` first; records before `root` are kept as they are.
+void stream_nearest_first(const std::vector<NodeRec> &nodes, uint32_t root, const float *point, std::vector<NodeRec> &out);
 uint32_t wide_nodes_build(const std::vector<NodeRec> &nodes, uint32_t root, const float *prim_boxes, std::vector<WideNode> &out);
 
 // ---- pieces with their own tests ----

@@ -109,6 +109,7 @@ _SIGS = {
     "rtx_scene_gamma_thresholds": (C.c_int, [C.c_void_p, f32p]),
     "rtx_scene_normals": (C.c_int, [C.c_void_p, f32p]),
     "rtx_scene_nodes": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "rtx_scene_primary_nodes": (C.c_int, [C.c_void_p, u32p, u32p]),
     "rtx_scene_ref_nodes": (C.c_int, [C.c_void_p, u32p]),
     "rtxh_camera_new": (None, [f32p] * 6),
     "rtxh_import_obj": (C.c_int, [C.c_char_p, C.POINTER(f32p)]),
@@ -354,6 +355,13 @@ class Scene:
         order = np.zeros(i["n_tris"], np.uint32)
         _check(_lib.rtx_scene_nodes(self._h, nd.ctypes.data_as(u32p), order.ctypes.data_as(u32p)), "rtx_scene_nodes")
         return nd, order
+
+    def primary_nodes(self):
+        """-> (records of the primary rays' stream, whether the scene has one of its own)"""
+        nd = np.zeros((self.info()["n_nodes"], 8), np.uint32)
+        own = C.c_uint32(0)
+        _check(_lib.rtx_scene_primary_nodes(self._h, nd.ctypes.data_as(u32p), C.cast(C.byref(own), u32p)), "rtx_scene_primary_nodes")
+        return nd, bool(own.value)
 
     def ref_nodes(self):
         nd = np.zeros((self.info()["n_ref_nodes"], 8), np.uint32)

@@ -282,6 +282,35 @@ def test_traversal_stream_is_well_formed(rtx, samples_half, accel, leaf_max):
             assert info["n_nodes"] == 2 * info["n_leaves"] - 1
 
 
+def test_primary_stream_is_the_same_tree_nearest_child_first(rtx, samples_half):
+    """The primary rays walk a stream of their own (scene_prep.h: PreparedScene::primary_nodes): well formed, the same
+    records as the shadow rays' stream (boxes and leaves, as a multiset), and at every inner node the child whose box centre
+    lies nearer the eye comes first.  A brute-force scene has none: its one stream serves both."""
+    tris, rgb = rtx.default_primitives([model("big_bunny.obj")])
+    LEAF = 0x80000000
+    with rtx.Scene(32, 32, tris, rgb, samples_half[:64]) as s:
+        nodes, order = s.nodes()
+        prim, own = s.primary_nodes()
+        assert own and prim.shape == nodes.shape
+        _check_stream(prim, order, tris, len(tris))
+        # the same boxes and leaf contents, in another order (links and second-child words differ)
+        key = lambda nd: sorted((r[0], r[1], r[2], r[4], r[5], r[6]) + ((r[7], r[3]) if r[7] & LEAF else (0, 0)) for r in nd.tolist())
+        assert key(nodes) == key(prim)
+        assert np.array_equal(prim[:2, [0, 1, 2, 4, 5, 6]], nodes[:2, [0, 1, 2, 4, 5, 6]])     # the root and the ground's leaf stay in front
+        eye = np.array([0.0, 100.0, 200.0])           # main.rs:353 (the default scene's camera)
+        f = prim.view(np.float32)
+        centre = 0.5 * f[:, 0:3].astype(np.float64) + 0.5 * f[:, 4:7].astype(np.float64)
+        d2 = ((centre - eye) ** 2).sum(axis=1)
+        inner = [i for i in range(2, len(prim)) if not prim[i, 7] & LEAF]     # (records 0, 1: the root and the ground's leaf)
+        assert len(inner) > 1000
+        for i in inner:
+            assert d2[i + 1] <= d2[int(prim[i, 7])]
+    with rtx.Scene(32, 32, tris[:40], rgb[:40], samples_half[:64], accel=1) as s:
+        nodes, _ = s.nodes()
+        prim, own = s.primary_nodes()
+        assert not own and np.array_equal(prim, nodes)
+
+
 def test_stream_degenerate_inputs(rtx, samples_half):
     """single triangle; many coincident triangles (no centroid spread: split by list position)."""
     one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)
