@@ -80,7 +80,10 @@ __device__ __forceinline__ bool j1_any_hit_cut_vec(const NodeRec *__restrict__ n
 {
     unsigned long long alive = ballot(r.active);
     if (ballot(r.active && !direction_is_regular(r.dx, r.dy, r.dz)) != 0ull)
-        return any_hit_cut<COUNT, true, SPHERES, true>(nodes_c, tris, shade, cut, n_cut, r, wc, n_global, first_global_ruled_out);
+    {
+        uint32_t first_entry = 0u;
+        return any_hit_cut<COUNT, true, SPHERES, true>(nodes_c, tris, shade, cut, n_cut, r, wc, n_global, first_global_ruled_out, first_entry);
+    }
     unsigned long long n_active = COUNT ? __popcll(alive) : 0ull;
     if (n_global != 0u) {
         const uint32_t first = first_global_ruled_out ? 1u : 0u;

@@ -1291,13 +1291,16 @@ __device__ __forceinline__ bool hit_wide(const WideNode RTX_CONSTANT *__restrict
 // visits a superset of the candidates the whole-stream walk would find among the occluders, and an any-hit result does
 // not depend on the order.  The upper levels of the tree, which the hundred chunks of a tile would otherwise descend a
 // hundred times, are walked once per tile.  cut: LDS, (begin, end) pairs.
+#ifndef RTX_CUT_RING
+#define RTX_CUT_RING 1
+#endif
 template <bool COUNT, bool SPHERES, bool USE_FAST, bool LEAN>
 __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                          const TriRec RTX_CONSTANT *__restrict__ tris,
                                          const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
                                          uint32_t n_cut, LaneRay &r, unsigned long long alive,
                                          unsigned long long n_active, WaveCounters &wc, uint32_t n_global,
-                                         uint32_t first_global)
+                                         uint32_t first_global, uint32_t &first_entry)
 {
     if (n_global != 0u) {   // the global triangles (the ground): every walk tests them, without a box test
         leaf_triangles<COUNT, true, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
@@ -1311,7 +1314,12 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
     // (One loop over all ranges — refilling [i, end) inside walk_range's loop — was measured too: the loop's two-way
     //  exit costs five scalar instructions per record there, this nesting three, the whole-stream walk none.)
     const uint32_t oct = USE_FAST ? walk_octant(r, alive) : kNone;   // once per chunk (advance_to_leaf); later walkers are among these lanes
-    for (uint32_t k = 0; k < n_cut; ++k) {
+    // The entries are walked in a ring that begins where the wavefront's previous walk ENDED — the entry in which its last
+    // ray found an occluder (RTX_CUT_RING).  The order is free (any-hit), and while a triangle rarely occludes the next
+    // light point's ray as well (profiles/r03/y_*), the PART of the mesh that does is the same for all of a tile's chunks:
+    // walks that end with every ray occluded are half of a frame's record fetches.
+    uint32_t k = (RTX_CUT_RING && first_entry < n_cut) ? first_entry : 0u;
+    for (uint32_t j = 0; j < n_cut; ++j, k = (k + 1u == n_cut) ? 0u : k + 1u) {
         const uint32_t *e = cut + kCutWords * k;
         NodeRec root;   // NodeDev order: lo.x lo.y hi.x hi.y lo.z hi.z link info
         root.bmin[0] = __uint_as_float(e[2]); root.bmin[1] = __uint_as_float(e[3]);
@@ -1332,7 +1340,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
             const uint32_t begin = __builtin_amdgcn_readfirstlane(e[0]), end = __builtin_amdgcn_readfirstlane(e[1]);
             alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc, oct);
         }
-        if (alive == 0ull) break;
+        if (alive == 0ull) { first_entry = k; break; }
     }
 }
 
@@ -1341,7 +1349,7 @@ __device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, const uint32_t *__restrict__ cut,
                                             uint32_t n_cut, LaneRay &r, WaveCounters &wc, uint32_t n_global,
-                                            bool first_global_ruled_out)
+                                            bool first_global_ruled_out, uint32_t &first_entry)
 {
     const unsigned long long alive = ballot(r.active);
     const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
@@ -1353,9 +1361,9 @@ __device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restri
     if (COUNT) n_active = __popcll(alive);
     if (FAST && all_regular)
         walk_cut<COUNT, SPHERES, true, LEAN>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global,
-                                             (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
+                                             (first_global_ruled_out && n_global != 0u) ? 1u : 0u, first_entry);
     else
-        walk_cut<COUNT, SPHERES, false, false>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global, 0u);
+        walk_cut<COUNT, SPHERES, false, false>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global, 0u, first_entry);
     return true;
 }
 
