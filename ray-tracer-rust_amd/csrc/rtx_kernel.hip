@@ -405,9 +405,6 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #ifndef RTX_CUT_DRAW_MIN
 #define RTX_CUT_DRAW_MIN 1
 #endif
-#ifndef RTX_STREAM_RING       // whole-stream form: a shadow walk begins where the previous one found its first occluder
-#define RTX_STREAM_RING 1
-#endif
 #ifndef RTX_WHOLE_DRAW_CHUNKS
 #define RTX_WHOLE_DRAW_CHUNKS 1
 #endif
@@ -1249,7 +1246,6 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     // ground-only frame, 81 % of big_bunny 4096x4096.
                     uint32_t c_first = wave * 64u;
                     uint32_t first_entry = 0u;        // the cut's entry this wavefront's next walk begins with (walk_cut)
-                    WalkRing ring = {kNone, kNone};   // whole-stream form: the record it begins at (walk_stream)
 #if RTX_OPEN_GROUND_LOOP && !RTX_WIDE_WALK
                     if (!WHOLE && full_tile && grey_tile && n_cut == 0u && have_plane && S.n_global == 1u && denom_d.usable) {
 #if !RTX_FULL_TILE_GENERAL      // the registers are this loop's alone: loaded here, dead behind it
@@ -1329,8 +1325,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                             else
 #endif
                             if (whole_tree)
-                                ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground,
-                                                                                            RTX_STREAM_RING ? &ring : nullptr);
+                                ok = any_hit<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, S.n_nodes, sr.ray, wc, S.n_global, no_ground);
 #if RTX_ABLATION
                             else if (S.j1_mode == 1u)
                                 ok = j1_any_hit_cut_vec<COUNT, SPHERES>(S.nodes, nodes, tris, S.shade, l_cut, n_cut, l_j1_win, sr.ray, wc, S.n_global, no_ground);
@@ -1651,7 +1646,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_WAVES)
-    RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD) RTX_SW(RTX_STREAM_RING) RTX_SW(RTX_WHOLE_DRAW_CHUNKS)
+    RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD) RTX_SW(RTX_WHOLE_DRAW_CHUNKS)
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
     RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)
     RTX_SW(RTX_TILE_BLOCKS) RTX_SW(RTX_TILE_PARTS_MAX) RTX_SW(RTX_TRIANGLE_EARLY_OUT)

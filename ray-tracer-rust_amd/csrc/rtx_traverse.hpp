@@ -972,16 +972,6 @@ __device__ __forceinline__ void advance_to_leaf(const NodeRec RTX_CONSTANT *__re
     visits = n;
 }
 
-// A whole-stream shadow walk as a ring (any_hit, RTX_STREAM_RING): it begins at `start` — the leaf in which the wavefront's
-// previous walk found its FIRST occluder — walks to the end of the stream and then from the stream's beginning up to
-// `start`.  A walk may begin at any record (culling keeps a superset, a record tested without its ancestors is still tested),
-// every record is met at most once, and an any-hit answer does not depend on the order; a wavefront whose rays all find
-// their occluders where the previous chunk's did never walks the stream's upper levels.
-struct WalkRing {
-    uint32_t start;        // record the next walk begins at (kNone / out of range: the stream's beginning)
-    uint32_t first_kill;   // out: record of the leaf in which this walk found its first occluder, kNone if none
-};
-
 // The walk over the records [i, end) with the multiply-based test, its box records stepped by advance_to_leaf; what
 // walk_range<.., USE_FAST = true> does, record for record.
 template <bool COUNT, bool SPHERES, bool ANYHIT>
@@ -990,7 +980,7 @@ __device__ __forceinline__ unsigned long long walk_range_fast(const NodeRec RTX_
                                                               const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
                                                               LaneRay &r, unsigned long long alive,
                                                               unsigned long long &n_active, WaveCounters &wc,
-                                                              uint32_t oct_known = kNone, WalkRing *ring = nullptr)
+                                                              uint32_t oct_known = kNone)
 {
     // (readfirstlane: wave-uniform values, but where the compiler has merged them over branches it may hold them in vector
     //  registers, which an "s" operand of the assembly cannot take)
@@ -1009,9 +999,7 @@ __device__ __forceinline__ unsigned long long walk_range_fast(const NodeRec RTX_
         else
             leaf_triangles<COUNT, ANYHIT, true>(tris, shade, info & kLeafIndexMask, link, r, alive, n_active, wc);
         if (ANYHIT) {   // lanes that found an occluder have left the walk; so does a wavefront without lanes
-            const unsigned long long now = ballot(r.active);
-            if (ring && now != alive && ring->first_kill == kNone) ring->first_kill = off >> 5;
-            alive = now;
+            alive = ballot(r.active);
             if (alive == 0ull) break;
             if (COUNT) n_active = __popcll(alive);
         }
@@ -1029,10 +1017,10 @@ __device__ __forceinline__ unsigned long long walk_range(const NodeRec RTX_CONST
                                                          const ShadeRec *__restrict__ shade, uint32_t i, uint32_t end,
                                                          LaneRay &r, unsigned long long alive,
                                                          unsigned long long &n_active, WaveCounters &wc,
-                                                         uint32_t oct_known = kNone, WalkRing *ring = nullptr)
+                                                         uint32_t oct_known = kNone)
 {
 #if RTX_ASM_WALK && RTX_CULL_FMA && RTX_CULL_INFLATED && !RTX_CULL_PACKED
-    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc, oct_known, ring);
+    if (USE_FAST) return walk_range_fast<COUNT, SPHERES, ANYHIT>(nodes, tris, shade, i, end, r, alive, n_active, wc, oct_known);
 #endif
     while (i < end) {
 #if RTX_ASM_NODE_LOAD
@@ -1094,7 +1082,7 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes, LaneRay &r,
                                             unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
-                                            uint32_t n_global, uint32_t first_global = 0u, WalkRing *ring = nullptr)
+                                            uint32_t n_global, uint32_t first_global = 0u)
 {
     // The root's own test is skipped when the root is an inner node (a stream of more than one record): culling
     // only has to be a superset, and nothing is lost — a candidate passes its own box, hence (section 2 of
@@ -1111,20 +1099,6 @@ __device__ __forceinline__ void walk_stream(const NodeRec RTX_CONSTANT *__restri
         }
         i = 2u;
     }
-    if (ANYHIT && USE_FAST && ring) {
-        ring->first_kill = kNone;
-        const uint32_t start = ring->start;
-        if (start > i && start < n_nodes) {
-            const uint32_t oct = walk_octant(r, alive);
-            alive = walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, start, n_nodes, r, alive, n_active, wc, oct, ring);
-            if (alive != 0ull)
-                (void)walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, i, start, r, alive, n_active, wc, oct, ring);
-        } else {
-            (void)walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, i, n_nodes, r, alive, n_active, wc, kNone, ring);
-        }
-        if (ring->first_kill != kNone) ring->start = ring->first_kill;
-        return;
-    }
     (void)walk_range<COUNT, SPHERES, ANYHIT, USE_FAST, LEAN>(nodes, tris, shade, i, n_nodes, r, alive, n_active, wc);
 }
 
@@ -1135,7 +1109,7 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
                                             const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                             LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
-                                            bool first_global_ruled_out = false, WalkRing *ring = nullptr)
+                                            bool first_global_ruled_out = false)
 {
     unsigned long long alive = ballot(r.active);   // the lanes still walking, as a scalar: every lane tests, these vote
     // direction classes: six compares voted one by one (direction_is_regular); the hard test runs only when some
@@ -1151,7 +1125,7 @@ __device__ __forceinline__ bool closest_hit(const NodeRec RTX_CONSTANT *__restri
     // two copies of the walk, chosen once: inside the loop the multiply-based test is then straight-line code (with
     // the choice inside the loop every node paid two more taken branches on the scalar unit)
     if (use_fast) walk_stream<COUNT, SPHERES, ANYHIT, true, LEAN>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global,
-                                                            (first_global_ruled_out && n_global != 0u) ? 1u : 0u, ring);
+                                                            (first_global_ruled_out && n_global != 0u) ? 1u : 0u);
     else walk_stream<COUNT, SPHERES, ANYHIT, false>(nodes, tris, shade, n_nodes, r, alive, n_active, wc, n_global);
     return true;
 }
@@ -1163,9 +1137,9 @@ __device__ __forceinline__ bool any_hit(const NodeRec RTX_CONSTANT *__restrict__
                                         const TriRec RTX_CONSTANT *__restrict__ tris,
                                         const ShadeRec *__restrict__ shade, uint32_t n_nodes,
                                         LaneRay &r, WaveCounters &wc, uint32_t n_global = 0u,
-                                        bool first_global_ruled_out = false, WalkRing *ring = nullptr)
+                                        bool first_global_ruled_out = false)
 {
-    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out, ring);
+    return closest_hit<COUNT, FAST, SPHERES, true, LEAN>(nodes, tris, shade, n_nodes, r, wc, n_global, first_global_ruled_out);
 }
 
 // ---- the wide walk (A/B builds only: -DRTX_WIDE_WALK=1 / -DRTX_PROBE_WIDE=1; librtx.so walks the binary stream) -------
@@ -1366,7 +1340,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
             const uint32_t begin = __builtin_amdgcn_readfirstlane(e[0]), end = __builtin_amdgcn_readfirstlane(e[1]);
             alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc, oct);
         }
-        if (alive == 0ull) { first_entry = k; break; }     // (the entry of the FIRST occluder, or of the most: fewer records, the same time)
+        if (alive == 0ull) { first_entry = k; break; }
     }
 }
 
