@@ -1340,7 +1340,7 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
             const uint32_t begin = __builtin_amdgcn_readfirstlane(e[0]), end = __builtin_amdgcn_readfirstlane(e[1]);
             alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, begin + 1u, end, r, alive, n_active, wc, oct);
         }
-        if (alive == 0ull) { first_entry = k; break; }
+        if (alive == 0ull) { first_entry = k; break; }     // (beginning at the entry of the FIRST occluder, or of the most: fewer records, the same time)
     }
 }
 
