@@ -224,6 +224,7 @@ rtx::DeviceScene device_scene(const RtxScene *scene, const DeviceState &st)
     S.j1_mode = 0u;
 #if RTX_ABLATION   // librtx_ablation.so only: one scene with and without per-tile cuts (tests/test_gpu_pipeline.py)
     if (const char *e = std::getenv("RTX_CUT_MAX_NODES")) S.cut_max_nodes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+    if (S.cut_max_nodes > rtx::kCutEndMask) S.cut_max_nodes = rtx::kCutEndMask;     // (a cut stream's record holds a 26-bit position)
     // ... and the north_star's LDS / reduction design as measurable variants (rtx_j1_ablation.hpp); modes 2, 3: triangles only
     if (const char *e = std::getenv("RTX_J1")) {
         const uint32_t m = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));

@@ -78,6 +78,10 @@ struct CutEntry {
 };
 static_assert(sizeof(CutEntry) == 40, "CutEntry is ten dwords");
 constexpr uint32_t kCutWords = sizeof(CutEntry) / 4u;
+#ifndef RTX_MAX_CUT
+#define RTX_MAX_CUT 16
+#endif
+#define RTX_MAX_CUT_VALUE static_cast<size_t>(RTX_MAX_CUT)
 struct StreamWorkspace {
     HitRec   *hits;      // one per primary hit, compacted per tile
     uint32_t *pix_slot;  // tiles x 64: hit record of the pixel, or 0xFFFFFFFF
@@ -90,6 +94,12 @@ struct StreamWorkspace {
     CutEntry *cut;       // tiles x kMaxCut: the subtrees the tile's shaft towards the light can touch — written by
                          // probe_kernel, walked by shade_tiles_kernel
 };
+// Behind the tiles' CutEntry arrays, in the same buffer: every tile's cut once more AS A STREAM — kMaxCut node records of
+// 32 bytes that the shading pass steps with the walk's own box step (rtx_traverse.hpp: walk_cut_stream): a real leaf's record
+// as it is; for an inner root a record that LOOKS like a leaf (bit 31) with the root's box, link = the root's position in the
+// node stream and info = kLeafFlag | kCutInnerFlag | the position behind its subtree.
+constexpr uint32_t kCutInnerFlag = 1u << 29, kCutEndMask = (1u << 26) - 1u;
+__host__ __device__ inline size_t cut_stream_offset(size_t tiles) { return (tiles * RTX_MAX_CUT_VALUE * 40u + 63u) & ~static_cast<size_t>(63u); }
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets, cut; };
 #ifndef RTX_MAX_CUT
 #define RTX_MAX_CUT 16

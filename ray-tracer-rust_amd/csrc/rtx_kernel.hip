@@ -405,6 +405,9 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #ifndef RTX_CUT_DRAW_MIN
 #define RTX_CUT_DRAW_MIN 1
 #endif
+#ifndef RTX_CUT_STREAM        // 1: a chunk steps its tile's cut as a stream of records (walk_cut_stream); 0: out of LDS (walk_cut)
+#define RTX_CUT_STREAM 1
+#endif
 #ifndef RTX_WHOLE_DRAW_CHUNKS
 #define RTX_WHOLE_DRAW_CHUNKS 1
 #endif
@@ -595,9 +598,14 @@ __device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ 
 // node's two children (the next record, and the one its `info` names) join the next frontier.  Entries are record
 // ranges [begin, end) of the stream.
 __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__ nodes, uint32_t root, const Shaft &sh,
-                                                     CutEntry *__restrict__ out, uint32_t *__restrict__ l_front, uint32_t lane,
-                                                     uint32_t &weight)
+                                                     CutEntry *__restrict__ out, NodeDev *__restrict__ out_stream,
+                                                     uint32_t *__restrict__ l_front, uint32_t lane, uint32_t &weight)
 {
+    // the entry once more as a record of the tile's cut stream (rtx_device.h: kCutInnerFlag)
+    auto stream_record = [](uint32_t at, bool leaf, NodeDev nd) {
+        if (!leaf) { nd.info = kLeafFlag | kCutInnerFlag | nd.link; nd.link = at; }
+        return nd;
+    };
     uint32_t my = root, n_front = 1u, n_out = 0u, w = 0u;
     for (;;) {
         const bool have = lane < n_front;
@@ -611,6 +619,7 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         if (n_out + n_leaf + 2u * n_exp > kMaxCut) {      // stop here: the passing nodes of this level are the rest of the cut
             if (pass) {
                 out[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
+                out_stream[n_out + (uint32_t)__popcll(m_pass & below)] = stream_record(my, leaf, nd);
                 const uint32_t size = leaf ? 1u : nd.link - my;
                 w += leaf ? 1u + 3u * nd.link : 4u + 6u * (31u - (uint32_t)__clz((int)size));
             }
@@ -619,6 +628,7 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         }
         if (pass && leaf) {
             out[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
+            out_stream[n_out + (uint32_t)__popcll(m_leaf & below)] = nd;
             w += 1u + 3u * nd.link;            // its box test and its primitive records
         }
         n_out += n_leaf;
@@ -755,7 +765,9 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         // the tree proper: behind the root and the global triangles' leaf when there are any (scene_prep.cpp)
         const uint32_t root = S.n_global != 0u ? 2u : 0u;
         if (root < S.n_nodes && S.n_nodes <= S.cut_max_nodes) {
-            n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut, l_front, lane, weight);
+            NodeDev *cut_stream = reinterpret_cast<NodeDev *>(reinterpret_cast<char *>(W.cut) + cut_stream_offset(n_tiles));
+            n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut,
+                                     cut_stream + (size_t)tile_id * kMaxCut, l_front, lane, weight);
         } else if (root < S.n_nodes) {
             // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
             // cut of sixteen subtrees prunes nothing, and what orders such a frame well is the length of a real walk — the
@@ -1144,6 +1156,9 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         const bool sample_major = (tflags & 1u) != 0u;
         const bool skip = (tflags & 2u) != 0u;      // already queued for the reference re-render
         const uint32_t n_cut = (tflags >> kTileCutShift) & 0xFFu;
+        // the tile's cut as a stream (rtx_device.h: kCutInnerFlag), behind the tiles' entry arrays
+        const NodeRec RTX_CONSTANT *cut_stream = (const NodeRec RTX_CONSTANT *)(
+            reinterpret_cast<const char *>(W.cut) + cut_stream_offset(n_tiles)) + (size_t)tile_id * kMaxCut;
         // whole-stream form: chunk 0 of a full sample-major tile was walked by probe_kernel (its probing walk); the answers
         // lie where a cut would (words 0 and 1: work-items 0 and 1 of wavefront 0, which is the wavefront that has chunk 0)
         const bool chunk0_kept = WHOLE && RTX_KEEP_PROBING_WALK != 0 && (tflags & kTileChunk0Kept) != 0u && parts_log == 0u &&
@@ -1331,7 +1346,11 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                                 ok = j1_any_hit_cut_vec<COUNT, SPHERES>(S.nodes, nodes, tris, S.shade, l_cut, n_cut, l_j1_win, sr.ray, wc, S.n_global, no_ground);
 #endif
                             else
+#if RTX_CUT_STREAM
+                                ok = any_hit_cut_stream<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, cut_stream, n_cut, sr.ray, wc, S.n_global, no_ground, first_entry);
+#else
                                 ok = any_hit_cut<COUNT, FAST, SPHERES, RTX_SHADE_LEAN_STEP != 0>(nodes, tris, S.shade, l_cut, n_cut, sr.ray, wc, S.n_global, no_ground, first_entry);
+#endif
                         }
 #endif
                         if (!ok && lane == 0) l_ctl[1] = 1u;
@@ -1574,7 +1593,7 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);   // streamed (ablation) pipeline only; 16 B
     b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts) * sizeof(uint32_t) : 0u;
-    b.cut = probe ? tiles * kMaxCut * sizeof(CutEntry) : 0u;
+    b.cut = probe ? cut_stream_offset(tiles) + tiles * kMaxCut * sizeof(NodeDev) : 0u;     // CutEntry arrays, then the cut streams
     return b;
 }
 
@@ -1642,7 +1661,7 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
-    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
+    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_WAVES)

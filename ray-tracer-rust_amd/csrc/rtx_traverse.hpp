@@ -1344,6 +1344,91 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
     }
 }
 
+// The same walk with the tile's cut AS A STREAM (rtx_device.h: kCutInnerFlag; written by probe_kernel beside the entries):
+// the roots' boxes are stepped by the walk's own box step — record by scalar load, ten vector instructions in the ray's
+// octant, no vote for a root that no ray passes — instead of out of LDS with vector operands (three LDS reads, sixteen
+// vector instructions and two votes per root, a dozen roots per chunk: as much as everything below them in a chunk that
+// finds no occluder).  The ring order is walk_cut's.
+template <bool COUNT, bool SPHERES, bool USE_FAST, bool LEAN>
+__device__ __forceinline__ void walk_cut_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                                const TriRec RTX_CONSTANT *__restrict__ tris,
+                                                const ShadeRec *__restrict__ shade,
+                                                const NodeRec RTX_CONSTANT *__restrict__ cut, uint32_t n_cut, LaneRay &r,
+                                                unsigned long long alive, unsigned long long n_active, WaveCounters &wc,
+                                                uint32_t n_global, uint32_t first_global, uint32_t &first_entry)
+{
+    if (n_global != 0u) {   // the global triangles (the ground): every walk tests them, without a box test
+        leaf_triangles<COUNT, true, USE_FAST>(tris, shade, first_global, n_global - first_global, r, alive, n_active, wc);
+        alive = ballot(r.active);
+        if (alive == 0ull) return;
+        if (COUNT) n_active = __popcll(alive);
+    }
+    const uint32_t oct = USE_FAST ? walk_octant(r, alive) : kNone;
+    uint32_t start = __builtin_amdgcn_readfirstlane((RTX_CUT_RING && first_entry < n_cut) ? first_entry << 5 : 0u);
+    uint32_t off = start, end_off = __builtin_amdgcn_readfirstlane(n_cut << 5);
+    for (;;) {
+        while (off < end_off) {
+            uint32_t link, info;
+#if RTX_ASM_WALK && RTX_CULL_FMA && RTX_CULL_INFLATED && !RTX_CULL_PACKED
+            if (USE_FAST) {
+                uint32_t visits = 0u;
+                advance_to_leaf<COUNT, false>(cut, off, end_off, alive, r, oct, link, info, visits, 0.0f);
+                if (COUNT) { wc.box_tests += n_active * visits; wc.node_visits += visits; }
+                if (info == 0u) break;
+            } else
+#endif
+            {
+                const NodeRec cur = load_node_at(cut, off >> 5);
+                if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+                if ((box_mask(USE_FAST, cur, r) & alive) == 0ull) { off += 32u; continue; }
+                link = cur.link;
+                info = cur.info;
+            }
+            if (info & kCutInnerFlag) {         // an inner root: link = its record, the low bits of info = behind its subtree
+                alive = walk_range<COUNT, SPHERES, true, USE_FAST, LEAN>(nodes, tris, shade, link + 1u, info & kCutEndMask, r, alive,
+                                                                         n_active, wc, oct);
+            } else {
+                if (SPHERES && (info & kSphereFlag))
+                    leaf_spheres<COUNT, true>(tris, shade, info & kLeafIndexMask, link, r, n_active, wc);
+                else
+                    leaf_triangles<COUNT, true, USE_FAST>(tris, shade, info & kLeafIndexMask, link, r, alive, n_active, wc);
+                alive = ballot(r.active);
+                if (COUNT) n_active = __popcll(alive);
+            }
+            if (alive == 0ull) { first_entry = off >> 5; return; }
+            off += 32u;
+        }
+        if (start == 0u) return;
+        off = 0u;               // the ring's second stretch: the entries in front of the one it began with
+        end_off = start;
+        start = 0u;
+    }
+}
+
+template <bool COUNT, bool FAST, bool SPHERES = false, bool LEAN = false>
+__device__ __forceinline__ bool any_hit_cut_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
+                                                   const TriRec RTX_CONSTANT *__restrict__ tris,
+                                                   const ShadeRec *__restrict__ shade,
+                                                   const NodeRec RTX_CONSTANT *__restrict__ cut, uint32_t n_cut, LaneRay &r,
+                                                   WaveCounters &wc, uint32_t n_global, bool first_global_ruled_out,
+                                                   uint32_t &first_entry)
+{
+    const unsigned long long alive = ballot(r.active);
+    const unsigned long long regular = ballot(fabsf(r.dx) >= 0x1p-60f) & ballot(fabsf(r.dx) <= 2.0f) &
+                                       ballot(fabsf(r.dy) >= 0x1p-60f) & ballot(fabsf(r.dy) <= 2.0f) &
+                                       ballot(fabsf(r.dz) >= 0x1p-60f) & ballot(fabsf(r.dz) <= 2.0f);
+    const bool all_regular = (alive & ~regular) == 0ull;          // direction classes: see closest_hit
+    if (!all_regular && ballot(r.active && direction_is_hard(r.dx, r.dy, r.dz)) != 0ull) return false;
+    unsigned long long n_active = 0;
+    if (COUNT) n_active = __popcll(alive);
+    if (FAST && all_regular)
+        walk_cut_stream<COUNT, SPHERES, true, LEAN>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global,
+                                                    (first_global_ruled_out && n_global != 0u) ? 1u : 0u, first_entry);
+    else
+        walk_cut_stream<COUNT, SPHERES, false, false>(nodes, tris, shade, cut, n_cut, r, alive, n_active, wc, n_global, 0u, first_entry);
+    return true;
+}
+
 template <bool COUNT, bool FAST, bool SPHERES = false, bool LEAN = false>
 __device__ __forceinline__ bool any_hit_cut(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                             const TriRec RTX_CONSTANT *__restrict__ tris,
