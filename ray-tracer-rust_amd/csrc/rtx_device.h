@@ -98,7 +98,10 @@ struct StreamWorkspace {
 // 32 bytes that the shading pass steps with the walk's own box step (rtx_traverse.hpp: walk_cut_stream): a real leaf's record
 // as it is; for an inner root a record that LOOKS like a leaf (bit 31) with the root's box, link = the root's position in the
 // node stream and info = kLeafFlag | kCutInnerFlag | the position behind its subtree.
+// A tile's stream has kMaxCut + 1 records: the last one holds the box around ALL of the cut's roots (a chunk whose rays
+// all miss it — most chunks that find no occluder — tests nothing else).
 constexpr uint32_t kCutInnerFlag = 1u << 29, kCutEndMask = (1u << 26) - 1u;
+constexpr uint32_t kCutStreamRecords = RTX_MAX_CUT + 1u;
 __host__ __device__ inline size_t cut_stream_offset(size_t tiles) { return (tiles * RTX_MAX_CUT_VALUE * 40u + 63u) & ~static_cast<size_t>(63u); }
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets, cut; };
 #ifndef RTX_MAX_CUT

@@ -408,6 +408,13 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #ifndef RTX_CUT_STREAM        // 1: a chunk steps its tile's cut as a stream of records (walk_cut_stream); 0: out of LDS (walk_cut)
 #define RTX_CUT_STREAM 1
 #endif
+// the entry form of a tile's cut (CutEntry, staged in LDS by a job) is read by the A/B forms only: the LDS walk, the wide
+// walk, the ablation library's variants
+#if RTX_ABLATION || RTX_WIDE_WALK || !RTX_CUT_STREAM
+#define kCutEntriesUsed true
+#else
+#define kCutEntriesUsed false
+#endif
 #ifndef RTX_WHOLE_DRAW_CHUNKS
 #define RTX_WHOLE_DRAW_CHUNKS 1
 #endif
@@ -607,6 +614,12 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         return nd;
     };
     uint32_t my = root, n_front = 1u, n_out = 0u, w = 0u;
+    const float inf = __builtin_inff();
+    float ulx = inf, uly = inf, ulz = inf, uhx = -inf, uhy = -inf, uhz = -inf;      // around the roots this work-item has written
+    auto around = [&](const NodeDev &nd) {
+        ulx = fminf(ulx, nd.lox); uly = fminf(uly, nd.loy); ulz = fminf(ulz, nd.loz);
+        uhx = fmaxf(uhx, nd.hix); uhy = fmaxf(uhy, nd.hiy); uhz = fmaxf(uhz, nd.hiz);
+    };
     for (;;) {
         const bool have = lane < n_front;
         NodeDev nd = {};
@@ -618,8 +631,9 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         const unsigned long long below = (1ull << lane) - 1ull;
         if (n_out + n_leaf + 2u * n_exp > kMaxCut) {      // stop here: the passing nodes of this level are the rest of the cut
             if (pass) {
-                out[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
+                if (kCutEntriesUsed) out[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
                 out_stream[n_out + (uint32_t)__popcll(m_pass & below)] = stream_record(my, leaf, nd);
+                around(nd);
                 const uint32_t size = leaf ? 1u : nd.link - my;
                 w += leaf ? 1u + 3u * nd.link : 4u + 6u * (31u - (uint32_t)__clz((int)size));
             }
@@ -627,8 +641,9 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
             break;
         }
         if (pass && leaf) {
-            out[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
+            if (kCutEntriesUsed) out[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
             out_stream[n_out + (uint32_t)__popcll(m_leaf & below)] = nd;
+            around(nd);
             w += 1u + 3u * nd.link;            // its box test and its primitive records
         }
         n_out += n_leaf;
@@ -646,6 +661,13 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         __builtin_amdgcn_wave_barrier();
     }
     weight = wave_sum(w);
+    if (n_out >= 2u) {   // the box around all roots: the stream's last record (walk_cut_stream reads it for cuts of two or more)
+        NodeDev all;
+        all.lox = wave_min(ulx); all.loy = wave_min(uly); all.loz = wave_min(ulz);
+        all.hix = wave_max(uhx); all.hiy = wave_max(uhy); all.hiz = wave_max(uhz);
+        all.link = 0u; all.info = 0u;
+        if (lane == 0) out_stream[kMaxCut] = all;
+    }
     return n_out;
 }
 
@@ -767,7 +789,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         if (root < S.n_nodes && S.n_nodes <= S.cut_max_nodes) {
             NodeDev *cut_stream = reinterpret_cast<NodeDev *>(reinterpret_cast<char *>(W.cut) + cut_stream_offset(n_tiles));
             n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut,
-                                     cut_stream + (size_t)tile_id * kMaxCut, l_front, lane, weight);
+                                     cut_stream + (size_t)tile_id * kCutStreamRecords, l_front, lane, weight);
         } else if (root < S.n_nodes) {
             // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
             // cut of sixteen subtrees prunes nothing, and what orders such a frame well is the length of a real walk — the
@@ -1146,7 +1168,10 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             }
         }
         static_assert(kCutWords * kMaxCut <= 64u * NW, "one word of the cut per work-item");
-        const uint32_t cut_word = threadIdx.x < kCutWords * kMaxCut ? reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x] : 0u;
+        // (the cut's entries go to LDS only where something reads them there — kCutEntriesUsed; the whole-stream form keeps
+        //  two words of answers in their place)
+        const uint32_t cut_word = threadIdx.x < (WHOLE ? 2u : (kCutEntriesUsed ? kCutWords * kMaxCut : 0u))
+                                      ? reinterpret_cast<const uint32_t *>(W.cut + (size_t)tile_id * kMaxCut)[threadIdx.x] : 0u;
         const uint32_t pix_word = wave == 0u ? W.pix_slot[(size_t)tile_id * 64u + lane] : kNone;   // (with the rest: not behind the descriptor)
         const TileDesc td = W.tiles[tile_id];
         const uint32_t n_all = __builtin_amdgcn_readfirstlane(td.n_hit);
@@ -1158,7 +1183,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
         const uint32_t n_cut = (tflags >> kTileCutShift) & 0xFFu;
         // the tile's cut as a stream (rtx_device.h: kCutInnerFlag), behind the tiles' entry arrays
         const NodeRec RTX_CONSTANT *cut_stream = (const NodeRec RTX_CONSTANT *)(
-            reinterpret_cast<const char *>(W.cut) + cut_stream_offset(n_tiles)) + (size_t)tile_id * kMaxCut;
+            reinterpret_cast<const char *>(W.cut) + cut_stream_offset(n_tiles)) + (size_t)tile_id * kCutStreamRecords;
         // whole-stream form: chunk 0 of a full sample-major tile was walked by probe_kernel (its probing walk); the answers
         // lie where a cut would (words 0 and 1: work-items 0 and 1 of wavefront 0, which is the wavefront that has chunk 0)
         const bool chunk0_kept = WHOLE && RTX_KEEP_PROBING_WALK != 0 && (tflags & kTileChunk0Kept) != 0u && parts_log == 0u &&
@@ -1174,7 +1199,7 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
             } else {                                                                 // the part's records [h0, h0 + n_hit) -> LDS [0, n_hit)
                 for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = tile_hits[h0 * kHitStride + k];
             }
-            if (threadIdx.x < kCutWords * n_cut) l_cut[threadIdx.x] = cut_word;
+            if (kCutEntriesUsed && threadIdx.x < kCutWords * n_cut) l_cut[threadIdx.x] = cut_word;
 #if RTX_ABLATION
             if (!WHOLE && S.j1_mode == 1u) {      // the stream window of this tile's cut -> LDS (rtx_j1_ablation.hpp)
                 __syncthreads();
@@ -1593,7 +1618,7 @@ StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec
     b.acc = S.nb_ray > 1u ? pixels * 3u * sizeof(float) : 0u;
     b.ctr = kStreamCtrWords * sizeof(uint32_t);   // streamed (ablation) pipeline only; 16 B
     b.buckets = probe ? (3u * kCostBuckets + tiles * kMaxTileParts) * sizeof(uint32_t) : 0u;
-    b.cut = probe ? cut_stream_offset(tiles) + tiles * kMaxCut * sizeof(NodeDev) : 0u;     // CutEntry arrays, then the cut streams
+    b.cut = probe ? cut_stream_offset(tiles) + tiles * kCutStreamRecords * sizeof(NodeDev) : 0u;     // CutEntry arrays, then the cut streams
     return b;
 }
 
@@ -1661,7 +1686,7 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
-    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
+    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_CUT_UNION_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_WAVES)

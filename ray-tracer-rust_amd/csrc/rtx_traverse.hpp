@@ -1349,6 +1349,12 @@ __device__ __forceinline__ void walk_cut(const NodeRec RTX_CONSTANT *__restrict_
 // octant, no vote for a root that no ray passes — instead of out of LDS with vector operands (three LDS reads, sixteen
 // vector instructions and two votes per root, a dozen roots per chunk: as much as everything below them in a chunk that
 // finds no occluder).  The ring order is walk_cut's.
+// Cuts of at least this many roots (>= 2: probe_kernel writes the box for those) are tested against the box around all of
+// them first; 0: none.  big_bunny 1080p: box records per frame -7.8 %, frame -0.8 %; 4096x4096 -0.7 % (from 4 roots on: +-0).
+#ifndef RTX_CUT_UNION_MIN
+#define RTX_CUT_UNION_MIN 2
+#endif
+static_assert(RTX_CUT_UNION_MIN == 0 || RTX_CUT_UNION_MIN >= 2, "the box around a cut's roots exists for cuts of two or more");
 template <bool COUNT, bool SPHERES, bool USE_FAST, bool LEAN>
 __device__ __forceinline__ void walk_cut_stream(const NodeRec RTX_CONSTANT *__restrict__ nodes,
                                                 const TriRec RTX_CONSTANT *__restrict__ tris,
@@ -1362,6 +1368,11 @@ __device__ __forceinline__ void walk_cut_stream(const NodeRec RTX_CONSTANT *__re
         alive = ballot(r.active);
         if (alive == 0ull) return;
         if (COUNT) n_active = __popcll(alive);
+    }
+    if (RTX_CUT_UNION_MIN != 0 && n_cut >= RTX_CUT_UNION_MIN) {     // the box around all roots (the stream's last record)
+        const NodeRec all = load_node_at(cut, kMaxCut);
+        if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
+        if ((box_mask(USE_FAST, all, r) & alive) == 0ull) return;
     }
     const uint32_t oct = USE_FAST ? walk_octant(r, alive) : kNone;
     uint32_t start = __builtin_amdgcn_readfirstlane((RTX_CUT_RING && first_entry < n_cut) ? first_entry << 5 : 0u);
