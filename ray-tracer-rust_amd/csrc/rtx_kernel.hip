@@ -1694,7 +1694,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
     RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)
     RTX_SW(RTX_TILE_BLOCKS) RTX_SW(RTX_TILE_PARTS_MAX) RTX_SW(RTX_TRIANGLE_EARLY_OUT)
-    RTX_SW(RTX_TRI_TOUCH_NEXT) RTX_SW(RTX_WALK_INTEGER_FLAGS) RTX_SW(RTX_WALK_SINGLE_EXIT)
+    RTX_SW(RTX_TRI_BOX_FIRST) RTX_SW(RTX_TRI_TOUCH_NEXT) RTX_SW(RTX_WALK_INTEGER_FLAGS) RTX_SW(RTX_WALK_SINGLE_EXIT)
     RTX_SW(RTX_WAVES_PER_SIMD) RTX_SW(RTX_WIDE_WALK) RTX_SW(RTX_XCD_QUEUES)
     RTX_SW(RTX_EXPERIMENT_TIMELINE) RTX_SW(RTX_EXPERIMENT_PHASES) RTX_SW(RTX_EXPERIMENT_PROBE_PHASES) RTX_SW(RTX_ABLATION);
 #undef RTX_SW

@@ -586,6 +586,9 @@ __device__ __forceinline__ TriRec load_tri_vec(const TriRec RTX_CONSTANT *base, 
 }
 #endif
 
+#ifndef RTX_TRI_BOX_FIRST      // 1: shadow walks test a primitive record's own box before the primitive; 2: all walks; 0: none
+#define RTX_TRI_BOX_FIRST 1
+#endif
 template <bool COUNT, bool ANYHIT = false, bool FAST_OK = false, bool VEC = false>
 __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__restrict__ tris,
                                                const ShadeRec *__restrict__ shade, uint32_t first, uint32_t count,
@@ -607,6 +610,17 @@ __device__ __forceinline__ void leaf_triangles(const TriRec RTX_CONSTANT *__rest
         const float e1x = tr->e1[0], e1y = tr->e1[1], e1z = tr->e1[2];
         const float e2x = tr->e2[0], e2y = tr->e2[1], e2z = tr->e2[2];
         if (COUNT) { wc.tri_tests += n_active; wc.tri_visits += 1; }
+#if RTX_TRI_BOX_FIRST
+        // The record's own box first (a candidate must pass it anyway: own_box_passes), for half of what the first part of the
+        // primitive test costs: a record whose box no walking ray passes is not tested at all.  (Culling only: the
+        // multiply-based test in its self-widening form — these boxes are the exact ones, not moved outwards like the
+        // stream's.  Only when few rays are left: the count and its branch cost more than the test saves.)
+        if ((ANYHIT || RTX_TRI_BOX_FIRST == 2) && FAST_OK && !VEC) {
+            // (the record's box is the exact one, not moved outwards like the stream's: the test widens itself, slab_fast_fma)
+            if ((ballot(slab_fast_fma(tr->bmin[0], tr->bmin[1], tr->bmin[2], tr->bmax[0], tr->bmax[1], tr->bmax[2], r.ix, r.iy, r.iz,
+                                      r.nx, r.ny, r.nz, r.slack0, r.behind)) & alive) == 0ull) continue;
+        }
+#endif
         const float pvx = r.dy * e2z - r.dz * e2y;                                   // :69
         const float pvy = r.dz * e2x - r.dx * e2z;
         const float pvz = r.dx * e2y - r.dy * e2x;
