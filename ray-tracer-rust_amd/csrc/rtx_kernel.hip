@@ -907,8 +907,11 @@ __device__ __forceinline__ uint32_t claim_job(uint32_t *__restrict__ buckets, ui
 #ifndef RTX_SPLIT_SCALE_MIN
 #define RTX_SPLIT_SCALE_MIN 0.25f
 #endif
+// (8 until the walks got the ring and the cut stream: a part is then mostly its fixed work, and four are enough — one
+//  share of an 8-way 1080p frame 0.246 -> 0.231 ms, of a 4-way / 2-way one and the whole frame equal; 16: +12 %, 2: +25 %;
+//  profiles/r03/xb_ab_parts_per_tile.log)
 #ifndef RTX_TILE_PARTS_MAX
-#define RTX_TILE_PARTS_MAX 8
+#define RTX_TILE_PARTS_MAX 4
 #endif
 constexpr uint32_t kMaxTileParts = RTX_TILE_PARTS_MAX;               // 1 = never split
 static_assert(kMaxTileParts >= 1u && kMaxTileParts <= 16u && (kMaxTileParts & (kMaxTileParts - 1u)) == 0u, "parts: a power of two <= 16");
@@ -977,11 +980,9 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
         const float per_wg = (float)scheduled / (float)shade_grid;
         const float scale = per_wg >= 16.0f ? 1.0f : (per_wg <= 16.0f * RTX_SPLIT_SCALE_MIN ? RTX_SPLIT_SCALE_MIN : per_wg * (1.0f / 16.0f));
         const float limit = split_share * scale * total / (float)shade_grid;
-        // ... and a part is a workgroup's fixed work plus a few chunks per wavefront: with the rays of the open ground as
-        // fast as they are now, eight parts are worth it only where a workgroup has fewer than three jobs, four otherwise
-        // (one GPU's share of a 1080p frame, 16 / 8 / 4 parts at most: 8-way, 2 jobs per workgroup, 0.296 / 0.266 / 0.279 ms;
-        // 4-way, 4 jobs, 0.450 / 0.417 / 0.378 ms; the full frame and 4096 x 4096 are equal —
-        // profiles/r02/j_ab_parts_per_tile.log)
+        // ... and a part is a workgroup's fixed work plus a few chunks per wavefront: round 2 found eight parts worth it
+        // only where a workgroup has fewer than three jobs, four otherwise (profiles/r02/j_ab_parts_per_tile.log); since
+        // round 3's walks four is the most anywhere (kMaxTileParts)
         const uint32_t most_parts = per_wg < 3.0f ? kMaxTileParts : (kMaxTileParts < 4u ? kMaxTileParts : 4u);
         uint32_t lg = 0u;
         while ((1u << lg) < most_parts && class_cost(tid) > limit * (float)(1u << lg)) ++lg;
