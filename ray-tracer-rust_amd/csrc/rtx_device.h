@@ -118,6 +118,7 @@ constexpr uint32_t kMaxCut = RTX_MAX_CUT;
 // entries (two words each, 128) had run.  Also <= 64: one wavefront holds the cut's frontier.  Below: an empty array.
 static_assert(kMaxCut >= 1u && kMaxCut <= 51u && kCutWords * kMaxCut <= 512u, "RTX_MAX_CUT: 1 .. 51 (one staged word per work-item of 512)");
 constexpr uint32_t kTileCutShift = 8u;       // TileDesc::flags
+constexpr uint32_t kTileCompactHits = 8u;    // TileDesc::flags: the tile's hit records are in the compact form (rtx_kernel.hip: compact_hit_word)
 constexpr uint32_t kTileChunk0Kept = 4u;     // TileDesc::flags: probe_kernel's probing walk answers the shading pass's chunk 0
 StreamWorkspaceBytes stream_workspace_bytes(const DeviceScene &S, const TileSpec &ts, uint32_t variant);
 constexpr uint32_t kCostBuckets = 64u;

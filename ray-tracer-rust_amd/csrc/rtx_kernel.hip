@@ -41,6 +41,19 @@ namespace {
 constexpr bool kOneSurfaceSampleMajor = RTX_ONE_SURFACE_SAMPLE_MAJOR != 0;
 // LDS hit record of the fused kernel: p_hit xyz, normal xyz, colour rgb, 3 spare floats
 constexpr uint32_t kHitStride = 12u;
+// Hit records of a tile whose hit pixels all lie on ONE triangle (the ground, walls: nine tiles in ten of the default
+// scene) in a compact form: the 64 slots hold 64 x 12 bytes of hit POINTS, then once the normal and the colour they share —
+// 792 bytes instead of 3072, written by probe_kernel and read by the tile's job (a 4096 x 4096 frame: 0.38 GB each way).
+// The job word says which form it is (the descriptor arrives with the records, not before them).  compact_hit_word: where
+// word k of the full form (record k / 12, word k % 12) lies in the compact one; kNone: a padding word (zero).
+#ifndef RTX_COMPACT_HITS
+#define RTX_COMPACT_HITS 1
+#endif
+__device__ __forceinline__ uint32_t compact_hit_word(uint32_t record, uint32_t word)
+{
+    return word < 3u ? record * 3u + word : (word < 9u ? 192u + word - 3u : kNone);
+}
+
 // Wavefronts per SIMD the register allocation is asked to allow.  8 (64 VGPRs) is 1.6 % faster on C3 but spills
 // 68 B per lane to scratch (measured +0.3 GB of HBM traffic per frame); 6 fits in 79 VGPRs with no scratch.
 #ifndef RTX_WAVES_PER_SIMD
@@ -748,6 +761,8 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         }
     }
     float hx = 0.0f, hy = 0.0f, hz = 0.0f;
+    const bool compact = RTX_COMPACT_HITS && one_surface && n_hit != 0u && (!SPHERES || S.shade[first_idx].kind == 0u);
+    if (compact) flags |= kTileCompactHits;
     if (hit) {
         const ShadeRec sh = S.shade[pr.best_idx];
         HitRec h;
@@ -757,7 +772,16 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         hit_normal<SPHERES>(sh, h.p[0], h.p[1], h.p[2], h.n[0], h.n[1], h.n[2]);     // main.rs:206
         h.rgb[0] = sh.rgb[0]; h.rgb[1] = sh.rgb[1]; h.rgb[2] = sh.rgb[2];            // main.rs:191
         h.pad[0] = h.pad[1] = h.pad[2] = 0.0f;
-        W.hits[(size_t)tile_id * 64u + slot] = h;
+        if (compact) {      // (compact_hit_word) one triangle: its normal and colour once, behind the 64 hit points
+            float *words = reinterpret_cast<float *>(W.hits + (size_t)tile_id * 64u);
+            words[3u * slot] = h.p[0]; words[3u * slot + 1u] = h.p[1]; words[3u * slot + 2u] = h.p[2];
+            if (slot == 0u) {
+                words[192] = h.n[0]; words[193] = h.n[1]; words[194] = h.n[2];
+                words[195] = h.rgb[0]; words[196] = h.rgb[1]; words[197] = h.rgb[2];
+            }
+        } else {
+            W.hits[(size_t)tile_id * 64u + slot] = h;
+        }
     }
     W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;
     // The tile's cut (shaft_cut above) and, from it, the tile's cost estimate: chunks x (a chunk's fixed work + what a
@@ -916,9 +940,9 @@ __device__ __forceinline__ uint32_t claim_job(uint32_t *__restrict__ buckets, ui
 constexpr uint32_t kMaxTileParts = RTX_TILE_PARTS_MAX;               // 1 = never split
 static_assert(kMaxTileParts >= 1u && kMaxTileParts <= 16u && (kMaxTileParts & (kMaxTileParts - 1u)) == 0u, "parts: a power of two <= 16");
 constexpr uint32_t kNotMine = 0xFFFFFFFEu;                          // shade_tiles_kernel: a pixel of another part of the tile
-// job = tile | part << 25 | log2(parts) << 29  (log2(parts) <= 4, so no job equals kNone)
-constexpr uint32_t kJobTileBits = 25u, kJobTileMask = (1u << kJobTileBits) - 1u, kJobPartsShift = 29u;
-
+// job = tile | part << 25 | log2(parts) << 28 | compact hit records << 30  (bit 31 stays clear: no job equals kNone)
+constexpr uint32_t kJobTileBits = 25u, kJobTileMask = (1u << kJobTileBits) - 1u, kJobPartsShift = 28u, kJobCompactShift = 30u;
+static_assert(kMaxTileParts <= 8u, "a job word holds three bits of part number and two of log2(parts)");
 // lower end of cost class k (cost_class above): k = 2 floor(log2 c) + (second bit of c) + 1
 __device__ __forceinline__ float class_cost(uint32_t k)
 {
@@ -1001,7 +1025,8 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(uint32_t n_tiles, Str
     if (key != kNone) {
         const uint32_t lg = parts_log[key];
         uint32_t *dst = W.buckets + kOrderList + start[key] + (slot << lg);
-        for (uint32_t p = 0; p < (1u << lg); ++p) dst[p] = i | (p << kJobTileBits) | (lg << kJobPartsShift);
+        const uint32_t form = (RTX_COMPACT_HITS && (W.tiles[i].flags & kTileCompactHits)) ? 1u << kJobCompactShift : 0u;
+        for (uint32_t p = 0; p < (1u << lg); ++p) dst[p] = i | (p << kJobTileBits) | (lg << kJobPartsShift) | form;
     }
 }
 
@@ -1152,7 +1177,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 #endif
         // part `part` of 2^parts_log of the tile: its hit records [h0, h0 + n_hit), the pixels they belong to, and (part 0)
         // the tile's pixels without a hit
-        const uint32_t tile_id = job & kJobTileMask, part = (job >> kJobTileBits) & 15u, parts_log = job >> kJobPartsShift;
+        const uint32_t tile_id = job & kJobTileMask, part = (job >> kJobTileBits) & 7u, parts_log = (job >> kJobPartsShift) & 3u;
+        const bool compact = RTX_COMPACT_HITS && ((job >> kJobCompactShift) & 1u) != 0u;
         uint32_t tile_x, tile_y;
         tile_xy(tile_id, tiles_x, RTX_TILE_BLOCKS != 0, tile_x, tile_y);
         // A whole tile's job requests everything it needs from HBM at once — the tile's descriptor, all 64 of its hit-record
@@ -1165,7 +1191,8 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
 #pragma unroll
             for (uint32_t j = 0; j < sizeof(hit_words) / sizeof(float); ++j) {
                 const uint32_t k = threadIdx.x + j * 64u * NW;
-                hit_words[j] = k < 64u * kHitStride ? tile_hits[k] : 0.0f;
+                const uint32_t at = compact ? compact_hit_word(k / kHitStride, k % kHitStride) : k;
+                hit_words[j] = (k < 64u * kHitStride && at != kNone) ? tile_hits[at] : 0.0f;
             }
         }
         static_assert(kCutWords * kMaxCut <= 64u * NW, "one word of the cut per work-item");
@@ -1198,7 +1225,10 @@ shade_tiles_kernel(DeviceScene S, TileSpec ts, uint32_t batch, uint32_t tiles_x,
                     if (k < n_hit * kHitStride) l_hit[k] = hit_words[j];
                 }
             } else {                                                                 // the part's records [h0, h0 + n_hit) -> LDS [0, n_hit)
-                for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) l_hit[k] = tile_hits[h0 * kHitStride + k];
+                for (uint32_t k = threadIdx.x; k < n_hit * kHitStride; k += 64u * NW) {
+                    const uint32_t at = compact ? compact_hit_word(h0 + k / kHitStride, k % kHitStride) : h0 * kHitStride + k;
+                    l_hit[k] = at != kNone ? tile_hits[at] : 0.0f;
+                }
             }
             if (kCutEntriesUsed && threadIdx.x < kCutWords * n_cut) l_cut[threadIdx.x] = cut_word;
 #if RTX_ABLATION
@@ -1686,7 +1716,7 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 #define RTX_SW(x) " " #x "=" RTX_SW_STR(x)
 extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
-    RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
+    RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_COMPACT_HITS) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_CUT_UNION_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
