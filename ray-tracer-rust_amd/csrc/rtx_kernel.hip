@@ -951,6 +951,14 @@ __device__ __forceinline__ float class_cost(uint32_t k)
     return lz ? (float)(2u + half) * (float)(1u << (lz - 1u)) : 1.0f;
 }
 
+// the words a launch's kernels count in, zeroed: queue[first, end) and buckets[0, n)
+__global__ void __launch_bounds__(256) reset_kernel(uint32_t *__restrict__ queue, uint32_t first, uint32_t end,
+                                                    uint32_t *__restrict__ buckets, uint32_t n)
+{
+    for (uint32_t i = first + threadIdx.x; i < end; i += 256u) queue[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) buckets[i] = 0u;
+}
+
 __global__ void __launch_bounds__(1024) count_classes_kernel(uint32_t n_tiles, StreamWorkspace W)
 {
     __shared__ uint32_t count[kCostBuckets];
@@ -1596,10 +1604,12 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
     if (n_tiles > kJobTileMask) return hipErrorInvalidValue;
     const uint64_t most_jobs = (uint64_t)n_tiles * kMaxTileParts;
     const uint32_t grid = most_jobs < static_cast<uint64_t>(cached_blocks) ? (uint32_t)most_jobs : static_cast<uint32_t>(cached_blocks);
-    if ((e = hipMemsetAsync(d_redo, 0, kQueueHeader * sizeof(uint32_t), stream)) != hipSuccess) return e;
     for (uint32_t r = 0; r < S.nb_ray; ++r) {                                        // main.rs:186
-        if (r != 0u && (e = hipMemsetAsync(d_redo + kQueueNextTile, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(W.buckets, 0, 3u * kCostBuckets * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        // one small kernel instead of two fills (a launch's dispatches are what an eighth of a 1080p frame is made of):
+        // the queue's header before the first primary ray, its tile cursor before the others; the order's histogram,
+        // cursors and claims every time
+        hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, stream, d_redo, r == 0u ? 0u : kQueueNextTile,
+                           r == 0u ? kQueueHeader : kQueueNextTile + 1u, W.buckets, 3u * kCostBuckets);
         hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>),
                            dim3(RTX_PROBE_XCD ? 512u * ((n_tiles + 511u) / 512u) : (n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
                            dim3(64 * RTX_PROBE_WAVES), 0, stream, S, ts, tiles_x, n_tiles,

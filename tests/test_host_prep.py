@@ -46,7 +46,7 @@ def test_product_library_has_one_pipeline_and_reads_no_environment(rtx):
     names = lambda b: set(m.decode() for m in re.findall(rb"_ZN3rtx\d+([a-z0-9_]+_kernel)I?", b)
                           if not m.startswith(b"__device_stub__"))
     kernels = names(blob)
-    assert kernels == {"probe_kernel", "count_classes_kernel", "order_tiles_kernel", "shade_tiles_kernel",
+    assert kernels == {"reset_kernel", "probe_kernel", "count_classes_kernel", "order_tiles_kernel", "shade_tiles_kernel",
                        "reference_tiles_kernel"}, kernels
     abl = os.path.join(ROOT, "ray-tracer-rust_amd", "librtx_ablation.so")
     assert os.path.exists(abl), "make -C ray-tracer-rust_amd/csrc ablation"

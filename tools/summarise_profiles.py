@@ -5,7 +5,7 @@ profiles/pmc_summary.json and profiles/traffic.json, and copy the evidence into 
     python tools/summarise_profiles.py gpurun_out/prof_j c3 profiles/r01 j
 
 Counters are averaged over the dispatches of the uncounted kernels (template argument COUNT = false) of the
-profiled run; one launch = probe_kernel + count_classes_kernel + order_tiles_kernel + shade_tiles_kernel + reference_tiles_kernel.
+profiled run; one launch = reset_kernel + probe_kernel + count_classes_kernel + order_tiles_kernel + shade_tiles_kernel + reference_tiles_kernel.
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
 (MI355X_MICROARCH.md), so the x2 figure is used as the upper bound, WRITE_SIZE as it is.
 """
@@ -17,7 +17,7 @@ import shutil
 import subprocess
 import sys
 
-KERNELS = {"probe_kernel<false": "probe", "order_tiles_kernel": "order", "count_classes_kernel": "count", "shade_tiles_kernel<false": "shade",
+KERNELS = {"reset_kernel": "reset", "probe_kernel<false": "probe", "order_tiles_kernel": "order", "count_classes_kernel": "count", "shade_tiles_kernel<false": "shade",
            "reference_tiles_kernel<false": "redo", "trace_shade_kernel<false": "fused"}
 N_SIMD = 1024               # 256 CUs x 4
 N_CU = 256
