@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
             W.hits[(size_t)tile_id * 64u + slot] = h;
         }
     }
-    W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;
+    if (n_hit != 0u) W.pix_slot[(size_t)tile_id * 64u + lane] = hit ? slot : kNone;   // (a tile without a hit has no job: nothing reads its slots)
     // The tile's cut (shaft_cut above) and, from it, the tile's cost estimate: chunks x (a chunk's fixed work + what a
     // walk of the cut fetches).
     unsigned long long cost = 0;
