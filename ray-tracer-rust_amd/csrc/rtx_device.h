@@ -101,15 +101,7 @@ struct StreamWorkspace {
 // A tile's stream has kMaxCut + 1 records: the last one holds the box around ALL of the cut's roots (a chunk whose rays
 // all miss it — most chunks that find no occluder — tests nothing else).
 constexpr uint32_t kCutInnerFlag = 1u << 29, kCutEndMask = (1u << 26) - 1u;
-// RTX_CUT_GROUPS = 1: the roots stand in groups of four, each group behind a record with the box around its four — an inner
-// node of the little stream, whose link skips the group: [G0 e0 e1 e2 e3 G1 e4 ...].  Roots next to each other in the cut
-// are next to each other in the tree (the descent is breadth first), so a chunk passes few of the group boxes.
-#ifndef RTX_CUT_GROUPS
-#define RTX_CUT_GROUPS 1
-#endif
-constexpr uint32_t kCutStreamRecords = RTX_MAX_CUT + (RTX_CUT_GROUPS ? (RTX_MAX_CUT + 3u) / 4u : 0u) + 1u;
-// records of a cut of n roots in its stream (without the box around all of them, which is the stream's last record)
-__host__ __device__ inline uint32_t cut_stream_length(uint32_t n) { return n + (RTX_CUT_GROUPS ? (n + 3u) / 4u : 0u); }
+constexpr uint32_t kCutStreamRecords = RTX_MAX_CUT + 1u;
 __host__ __device__ inline size_t cut_stream_offset(size_t tiles) { return (tiles * RTX_MAX_CUT_VALUE * 40u + 63u) & ~static_cast<size_t>(63u); }
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets, cut; };
 #ifndef RTX_MAX_CUT

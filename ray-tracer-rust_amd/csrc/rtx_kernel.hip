@@ -619,8 +619,7 @@ __device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ 
 // ranges [begin, end) of the stream.
 __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__ nodes, uint32_t root, const Shaft &sh,
                                                      CutEntry *__restrict__ out, NodeDev *__restrict__ out_stream,
-                                                     uint32_t *__restrict__ l_front, NodeDev *__restrict__ l_roots, uint32_t lane,
-                                                     uint32_t &weight)
+                                                     uint32_t *__restrict__ l_front, uint32_t lane, uint32_t &weight)
 {
     // the entry once more as a record of the tile's cut stream (rtx_device.h: kCutInnerFlag)
     auto stream_record = [](uint32_t at, bool leaf, NodeDev nd) {
@@ -628,6 +627,12 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         return nd;
     };
     uint32_t my = root, n_front = 1u, n_out = 0u, w = 0u;
+    const float inf = __builtin_inff();
+    float ulx = inf, uly = inf, ulz = inf, uhx = -inf, uhy = -inf, uhz = -inf;      // around the roots this work-item has written
+    auto around = [&](const NodeDev &nd) {
+        ulx = fminf(ulx, nd.lox); uly = fminf(uly, nd.loy); ulz = fminf(ulz, nd.loz);
+        uhx = fmaxf(uhx, nd.hix); uhy = fmaxf(uhy, nd.hiy); uhz = fmaxf(uhz, nd.hiz);
+    };
     for (;;) {
         const bool have = lane < n_front;
         NodeDev nd = {};
@@ -640,7 +645,8 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         if (n_out + n_leaf + 2u * n_exp > kMaxCut) {      // stop here: the passing nodes of this level are the rest of the cut
             if (pass) {
                 if (kCutEntriesUsed) out[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
-                l_roots[n_out + (uint32_t)__popcll(m_pass & below)] = stream_record(my, leaf, nd);
+                out_stream[n_out + (uint32_t)__popcll(m_pass & below)] = stream_record(my, leaf, nd);
+                around(nd);
                 const uint32_t size = leaf ? 1u : nd.link - my;
                 w += leaf ? 1u + 3u * nd.link : 4u + 6u * (31u - (uint32_t)__clz((int)size));
             }
@@ -649,7 +655,8 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         }
         if (pass && leaf) {
             if (kCutEntriesUsed) out[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
-            l_roots[n_out + (uint32_t)__popcll(m_leaf & below)] = nd;
+            out_stream[n_out + (uint32_t)__popcll(m_leaf & below)] = nd;
+            around(nd);
             w += 1u + 3u * nd.link;            // its box test and its primitive records
         }
         n_out += n_leaf;
@@ -667,36 +674,12 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         __builtin_amdgcn_wave_barrier();
     }
     weight = wave_sum(w);
-    // The roots, one per work-item now, go to the tile's stream: in groups of four behind the box around each group
-    // (rtx_device.h: RTX_CUT_GROUPS), the box around all of them in the stream's last record.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (n_out != 0u) {
-        const float inf = __builtin_inff();
-        const bool mine = lane < n_out;
-        NodeDev e = {inf, inf, -inf, -inf, inf, -inf, 0u, 0u};
-        if (mine) e = l_roots[lane];
-        float glx = e.lox, gly = e.loy, glz = e.loz, ghx = e.hix, ghy = e.hiy, ghz = e.hiz;
-#pragma unroll
-        for (int m = 1; m <= 2; m <<= 1) {      // over the four lanes of a group
-            glx = fminf(glx, __shfl_xor(glx, m)); gly = fminf(gly, __shfl_xor(gly, m)); glz = fminf(glz, __shfl_xor(glz, m));
-            ghx = fmaxf(ghx, __shfl_xor(ghx, m)); ghy = fmaxf(ghy, __shfl_xor(ghy, m)); ghz = fmaxf(ghz, __shfl_xor(ghz, m));
-        }
-        const uint32_t length = cut_stream_length(n_out);
-        if (RTX_CUT_GROUPS) {
-            if (mine) out_stream[lane + (lane >> 2) + 1u] = e;
-            if (mine && (lane & 3u) == 0u) {
-                const uint32_t next = 5u * ((lane >> 2) + 1u);
-                out_stream[5u * (lane >> 2)] = NodeDev{glx, gly, ghx, ghy, glz, ghz, next < length ? next : length, 0u};
-            }
-        } else if (mine) {
-            out_stream[lane] = e;
-        }
-        if (n_out >= 2u) {   // (walk_cut_stream reads it for cuts of two roots or more)
-            const NodeDev all = {wave_min(glx), wave_min(gly), wave_max(ghx), wave_max(ghy), wave_min(glz), wave_max(ghz), 0u, 0u};
-            if (lane == 0) out_stream[kCutStreamRecords - 1u] = all;
-        }
+    if (n_out >= 2u) {   // the box around all roots: the stream's last record (walk_cut_stream reads it for cuts of two or more)
+        NodeDev all;
+        all.lox = wave_min(ulx); all.loy = wave_min(uly); all.loz = wave_min(ulz);
+        all.hix = wave_max(uhx); all.hiy = wave_max(uhy); all.hiz = wave_max(uhz);
+        all.link = 0u; all.info = 0u;
+        if (lane == 0) out_stream[kMaxCut] = all;
     }
     return n_out;
 }
@@ -710,7 +693,6 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
     // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no barrier; LDS only inside shaft_cut)
     __shared__ uint32_t l_front_all[RTX_PROBE_WAVES][128];   // the cut's next frontier: node, subtree size
-    __shared__ NodeDev l_roots_all[RTX_PROBE_WAVES][kMaxCut];  // the cut's roots as records, until the descent is over
 #if RTX_ABLATION
     __shared__ __align__(16) uint32_t l_j1_block[RTX_PROBE_WAVES][kJ1BlockWords];   // RTX_J1=2: a block of 64 primitive records
 #endif
@@ -831,7 +813,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         if (root < S.n_nodes && S.n_nodes <= S.cut_max_nodes) {
             NodeDev *cut_stream = reinterpret_cast<NodeDev *>(reinterpret_cast<char *>(W.cut) + cut_stream_offset(n_tiles));
             n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut,
-                                     cut_stream + (size_t)tile_id * kCutStreamRecords, l_front, l_roots_all[wave_in_group], lane, weight);
+                                     cut_stream + (size_t)tile_id * kCutStreamRecords, l_front, lane, weight);
         } else if (root < S.n_nodes) {
             // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
             // cut of sixteen subtrees prunes nothing, and what orders such a frame well is the length of a real walk — the
@@ -1745,7 +1727,7 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
     RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_COMPACT_HITS) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
-    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_GROUPS) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_CUT_UNION_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
+    RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_CUT_UNION_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_WAVES)

@@ -1384,14 +1384,13 @@ __device__ __forceinline__ void walk_cut_stream(const NodeRec RTX_CONSTANT *__re
         if (COUNT) n_active = __popcll(alive);
     }
     if (RTX_CUT_UNION_MIN != 0 && n_cut >= RTX_CUT_UNION_MIN) {     // the box around all roots (the stream's last record)
-        const NodeRec all = load_node_at(cut, kCutStreamRecords - 1u);
+        const NodeRec all = load_node_at(cut, kMaxCut);
         if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
         if ((box_mask(USE_FAST, all, r) & alive) == 0ull) return;
     }
     const uint32_t oct = USE_FAST ? walk_octant(r, alive) : kNone;
-    const uint32_t length = cut_stream_length(n_cut);      // roots and, in front of every four, the box around them (RTX_CUT_GROUPS)
-    uint32_t start = __builtin_amdgcn_readfirstlane((RTX_CUT_RING && first_entry < length) ? first_entry << 5 : 0u);
-    uint32_t off = start, end_off = __builtin_amdgcn_readfirstlane(length << 5);
+    uint32_t start = __builtin_amdgcn_readfirstlane((RTX_CUT_RING && first_entry < n_cut) ? first_entry << 5 : 0u);
+    uint32_t off = start, end_off = __builtin_amdgcn_readfirstlane(n_cut << 5);
     for (;;) {
         while (off < end_off) {
             uint32_t link, info;
@@ -1406,12 +1405,7 @@ __device__ __forceinline__ void walk_cut_stream(const NodeRec RTX_CONSTANT *__re
             {
                 const NodeRec cur = load_node_at(cut, off >> 5);
                 if (COUNT) { wc.box_tests += n_active; wc.node_visits += 1; }
-                const bool passed = (box_mask(USE_FAST, cur, r) & alive) != 0ull;
-                if (!(cur.info >> 31)) {        // the box around a group of roots: into the group, or behind it
-                    off = __builtin_amdgcn_readfirstlane(passed ? off + 32u : cur.link << 5);
-                    continue;
-                }
-                if (!passed) { off += 32u; continue; }
+                if ((box_mask(USE_FAST, cur, r) & alive) == 0ull) { off += 32u; continue; }
                 link = cur.link;
                 info = cur.info;
             }
