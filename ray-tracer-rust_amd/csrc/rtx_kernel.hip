@@ -428,6 +428,23 @@ constexpr uint32_t kChunkFixedCost = 8u;
 #else
 #define kCutEntriesUsed false
 #endif
+// Wavefronts per SIMD probe_kernel's register allocation must allow: a 4096 x 4096 frame's 262,144 one-wavefront workgroups
+// are bound by how many of them are resident (the probing walk of cut tiles brought the kernel to 106 scalar registers: 7)
+#ifndef RTX_PROBE_WAVES_PER_SIMD
+#define RTX_PROBE_WAVES_PER_SIMD 8
+#endif
+#ifndef RTX_PROBE_CUT_TILES           // 1: one-surface tiles with a cut are probed by a real walk of light sample 0 (probe_kernel)
+#define RTX_PROBE_CUT_TILES 1
+#endif
+#ifndef RTX_PROBE_MIX                 // the tile's weight from that walk alone (0), the larger of walk and proxy (1), half the proxy + the walk (2)
+#define RTX_PROBE_MIX 2
+#endif
+#ifndef RTX_PROBE_VISIT_SCALE         // a record of that walk in the units of the cut's proxy
+#define RTX_PROBE_VISIT_SCALE 6u
+#endif
+#ifndef RTX_COST_MIXED_TILES_TWICE
+#define RTX_COST_MIXED_TILES_TWICE 1
+#endif
 #ifndef RTX_WHOLE_DRAW_CHUNKS
 #define RTX_WHOLE_DRAW_CHUNKS 1
 #endif
@@ -613,13 +630,34 @@ __device__ __forceinline__ uint32_t shaft_cut_wide(const WideNode *__restrict__ 
     return n_out;
 }
 
+// probe_kernel's probing walk of a one-surface tile with a cut: the tile's hit pixels towards one light point, through the
+// cut's entry form in LDS; returns the records the walk fetched.  (Inlined: as a CALLED function — to keep its registers
+// out of probe_kernel's, which every tile of a frame pays for — one bench run in three FAILED on the GPU box; not pursued.)
+template <bool FAST, bool SPHERES>
+__device__ __forceinline__ uint32_t probe_cut_walk(const NodeRec RTX_CONSTANT *nodes, const TriRec RTX_CONSTANT *tris,
+                                                             const ShadeRec *shade, const uint32_t *l_entries, uint32_t n_cut,
+                                                             uint32_t n_global, const float *light_point, bool hit, float hx, float hy,
+                                                             float hz)
+{
+    const float vx = light_point[0] - hx, vy = light_point[1] - hy, vz = light_point[2] - hz;     // main.rs:201-202, as shadow_ray_at
+    float dist_light, sx, sy, sz;
+    (void)length_and_direction(vx, vy, vz, dist_light, sx, sy, sz);
+    LaneRay sr = make_ray(hit, hx, hy, hz, sx, sy, sz);
+    sr.limit = dist_light;
+    WaveCounters probe;
+    uint32_t first_entry = 0u;
+    (void)any_hit_cut<true, FAST, SPHERES>(nodes, tris, shade, l_entries, n_cut, sr, probe, n_global, false, first_entry);
+    return (uint32_t)(probe.node_visits + probe.tri_visits);
+}
+
 // The same descent over the binary stream (what librtx.so ships; the wide form above is kept for A/B, DESIGN.md section
 // 4): one stream record per work-item, its own box against the shaft; a leaf that meets it becomes an entry, an inner
 // node's two children (the next record, and the one its `info` names) join the next frontier.  Entries are record
 // ranges [begin, end) of the stream.
 __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__ nodes, uint32_t root, const Shaft &sh,
                                                      CutEntry *__restrict__ out, NodeDev *__restrict__ out_stream,
-                                                     uint32_t *__restrict__ l_front, uint32_t lane, uint32_t &weight)
+                                                     uint32_t *__restrict__ l_front, CutEntry *__restrict__ l_entries,
+                                                     uint32_t lane, uint32_t &weight)
 {
     // the entry once more as a record of the tile's cut stream (rtx_device.h: kCutInnerFlag)
     auto stream_record = [](uint32_t at, bool leaf, NodeDev nd) {
@@ -645,6 +683,7 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         if (n_out + n_leaf + 2u * n_exp > kMaxCut) {      // stop here: the passing nodes of this level are the rest of the cut
             if (pass) {
                 if (kCutEntriesUsed) out[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
+                l_entries[n_out + (uint32_t)__popcll(m_pass & below)] = CutEntry{my, leaf ? my + 1u : nd.link, nd};
                 out_stream[n_out + (uint32_t)__popcll(m_pass & below)] = stream_record(my, leaf, nd);
                 around(nd);
                 const uint32_t size = leaf ? 1u : nd.link - my;
@@ -655,6 +694,7 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
         }
         if (pass && leaf) {
             if (kCutEntriesUsed) out[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
+            l_entries[n_out + (uint32_t)__popcll(m_leaf & below)] = CutEntry{my, my + 1u, nd};
             out_stream[n_out + (uint32_t)__popcll(m_leaf & below)] = nd;
             around(nd);
             w += 1u + 3u * nd.link;            // its box test and its primitive records
@@ -684,8 +724,10 @@ __device__ __forceinline__ uint32_t shaft_cut_binary(const NodeDev *__restrict__
     return n_out;
 }
 
-template <bool COUNT, bool FAST, bool SPHERES>
-__global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
+// WHOLE: the scene does not cut per tile (S.n_nodes > S.cut_max_nodes: shade_tiles_kernel's whole-stream form follows) — an
+// instantiation of its own, so that each carries one probing walk only (the kernel is short of scalar registers)
+template <bool COUNT, bool FAST, bool SPHERES, bool WHOLE>
+__global__ void __launch_bounds__(64 * RTX_PROBE_WAVES, RTX_PROBE_WAVES_PER_SIMD) probe_kernel(DeviceScene S, TileSpec ts, uint32_t tiles_x, uint32_t n_tiles,
                                                    uint32_t r, StreamWorkspace W, uint8_t *__restrict__ out,
                                                    uint32_t *__restrict__ queue, unsigned long long *__restrict__ counters)
 {
@@ -693,6 +735,7 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
     const TriRec RTX_CONSTANT *tris = (const TriRec RTX_CONSTANT *)S.tris;
     // one wavefront per tile, RTX_PROBE_WAVES independent wavefronts per workgroup (no barrier; LDS only inside shaft_cut)
     __shared__ uint32_t l_front_all[RTX_PROBE_WAVES][128];   // the cut's next frontier: node, subtree size
+    __shared__ CutEntry l_entries_all[RTX_PROBE_WAVES][kMaxCut];   // the tile's cut in its entry form, for the probing walk
 #if RTX_ABLATION
     __shared__ __align__(16) uint32_t l_j1_block[RTX_PROBE_WAVES][kJ1BlockWords];   // RTX_J1=2: a block of 64 primitive records
 #endif
@@ -810,11 +853,29 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
 #else
         // the tree proper: behind the root and the global triangles' leaf when there are any (scene_prep.cpp)
         const uint32_t root = S.n_global != 0u ? 2u : 0u;
-        if (root < S.n_nodes && S.n_nodes <= S.cut_max_nodes) {
+        if (!WHOLE && root < S.n_nodes) {
             NodeDev *cut_stream = reinterpret_cast<NodeDev *>(reinterpret_cast<char *>(W.cut) + cut_stream_offset(n_tiles));
             n_cut = shaft_cut_binary(reinterpret_cast<const NodeDev *>(S.nodes), root, sh, W.cut + (size_t)tile_id * kMaxCut,
-                                     cut_stream + (size_t)tile_id * kCutStreamRecords, l_front, lane, weight);
-        } else if (root < S.n_nodes) {
+                                     cut_stream + (size_t)tile_id * kCutStreamRecords, l_front, l_entries_all[wave_in_group], lane, weight);
+            // A one-surface tile with a cut — the ground in and around the mesh's shadow — is probed by a REAL walk as well:
+            // its hit pixels towards light sample 0, through the cut (the entry form, out of LDS: the stream just written is
+            // not to be read back through the scalar cache by the kernel that wrote it).  The cut's proxy cannot tell a tile
+            // in the open (its chunks pass no root) from one in the umbra (every ray walks until it is occluded): within one
+            // cost class the measured times spread 50 ... 770 us (tools/tile_timeline.py), and the costliest tiles, started
+            // late, are the frame's tail.  (Keeping the walk's answers as the shading pass's chunk 0, as the whole-stream form
+            // does, was measured too: the shading pass's general loop pays more for the case than a walk in a hundred saves.
+            // Skipping the walk in wavefronts already at work for 6 / 12 / 25 us — tiles beside the silhouette — as well: no.)
+            if (RTX_PROBE_CUT_TILES && n_cut != 0u && (flags & 1u)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t walked_weight = RTX_PROBE_VISIT_SCALE *
+                    probe_cut_walk<FAST, SPHERES>(nodes, tris, S.shade, reinterpret_cast<const uint32_t *>(l_entries_all[wave_in_group]), n_cut,
+                                                  S.n_global, S.light_points + 3u * (r * S.nb_light), hit, hx, hy, hz);
+                weight = RTX_PROBE_MIX == 1 ? (weight > walked_weight ? weight : walked_weight)
+                       : RTX_PROBE_MIX == 2 ? weight / 2u + walked_weight : walked_weight;
+            }
+        } else if (WHOLE && root < S.n_nodes) {
             // A scene of many small primitives (BASELINE configs[4]): nearly every tile's shaft meets thousands of leaves, a
             // cut of sixteen subtrees prunes nothing, and what orders such a frame well is the length of a real walk — the
             // tile's hit pixels towards light sample 0, its result unused.  No cut is written: shade_tiles_kernel's
@@ -845,6 +906,11 @@ __global__ void __launch_bounds__(64 * RTX_PROBE_WAVES) probe_kernel(DeviceScene
         }
 #endif
         cost = (unsigned long long)(kChunkFixedCost + weight) * n_chunks;
+        // A tile numbered pixel-major — hit pixels on several primitives: the mesh's own surface and its silhouette — takes
+        // about twice as long as a one-surface tile of the same proxy (its rays start INSIDE the boxes they walk; measured per
+        // cost class with tools/tile_timeline.py: x1.9 ... x2.5), and the order and the splitting should know: the costliest
+        // tiles of a frame are of this kind, and one of them started late is the frame's tail.
+        if (RTX_COST_MIXED_TILES_TWICE && !(flags & 1u) && n_cut != 0u) cost *= 2u;
     }
     // A tile without a hit is finished here (main.rs:235: the sums stay as they are), a queued tile belongs to the
     // reference re-render: neither is scheduled for shade_tiles_kernel (cost class kNone).
@@ -1610,7 +1676,7 @@ hipError_t launch_probe(const DeviceScene &S, const TileSpec &ts, uint8_t *d_out
         // cursors and claims every time
         hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(256), 0, stream, d_redo, r == 0u ? 0u : kQueueNextTile,
                            r == 0u ? kQueueHeader : kQueueNextTile + 1u, W.buckets, 3u * kCostBuckets);
-        hipLaunchKernelGGL((probe_kernel<COUNT, FAST, SPHERES>),
+        hipLaunchKernelGGL(whole ? (probe_kernel<COUNT, FAST, SPHERES, true>) : (probe_kernel<COUNT, FAST, SPHERES, false>),
                            dim3(RTX_PROBE_XCD ? 512u * ((n_tiles + 511u) / 512u) : (n_tiles + RTX_PROBE_WAVES - 1u) / RTX_PROBE_WAVES),
                            dim3(64 * RTX_PROBE_WAVES), 0, stream, S, ts, tiles_x, n_tiles,
                            r, W, d_out, d_redo, d_counters);
@@ -1726,11 +1792,11 @@ hipError_t launch_trace_shade(const DeviceScene &S, const TileSpec &ts, uint8_t 
 #define RTX_SW(x) " " #x "=" RTX_SW_STR(x)
 extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_switches_text[] = "rtx-build-switches:"
     RTX_SW(RTX_ASM_NODE_LOAD) RTX_SW(RTX_ASM_TRI_LOAD) RTX_SW(RTX_ASM_WALK)
-    RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_COMPACT_HITS) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
+    RTX_SW(RTX_CLAIM_RUN_LOG) RTX_SW(RTX_COMPACT_HITS) RTX_SW(RTX_COST_MIXED_TILES_TWICE) RTX_SW(RTX_CULL_FMA) RTX_SW(RTX_CULL_INFLATED)
     RTX_SW(RTX_CULL_PACKED) RTX_SW(RTX_CUT_DRAW_MIN) RTX_SW(RTX_CUT_RING) RTX_SW(RTX_CUT_STREAM) RTX_SW(RTX_CUT_UNION_MIN) RTX_SW(RTX_FULL_TILE_GENERAL) RTX_SW(RTX_FULL_TILE_PATH)
     RTX_SW(RTX_LIGHTWARD_ORDER) RTX_SW(RTX_LIGHT_BATCH) RTX_SW(RTX_MAX_CUT) RTX_SW(RTX_PRUNE_CLOSEST)
     RTX_SW(RTX_OCTANT_STEP) RTX_SW(RTX_ONE_SURFACE_SAMPLE_MAJOR) RTX_SW(RTX_OPEN_GROUND_LOOP)
-    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_WAVES)
+    RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_CUT_TILES) RTX_SW(RTX_PROBE_MIX) RTX_SW(RTX_PROBE_VISIT_SCALE) RTX_SW(RTX_PROBE_WAVES) RTX_SW(RTX_PROBE_WAVES_PER_SIMD)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD) RTX_SW(RTX_WHOLE_DRAW_CHUNKS)
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
     RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)

@@ -50,6 +50,13 @@ for name, m0 in (("sample-major (one surface)", work & ((flags & 1) != 0)), ("pi
         m = m0 & (us >= a) & (us < b)
         if m.any():
             print("    %5.0f..%5.0f us: %7d tiles  %9.0f us (%4.1f %% of the frame)" % (a, min(b, 99999), int(m.sum()), us[m].sum(), 100 * us[m].sum() / us.sum()))
+# the estimate against the measurement: per cost class (what the order and the splitting go by) the tiles' measured durations
+print("cost class: tiles, measured us mean / min / max, of which pixel-major")
+for k in sorted(set(cls[work].tolist())):
+    m = work & (cls == k)
+    print("    class %2d: %6d tiles  %8.1f / %7.1f / %7.1f us   pixel-major %5d (mean %7.1f us)" % (
+        k, int(m.sum()), us[m].mean(), us[m].min(), us[m].max(), int((m & ((flags & 1) == 0)).sum()),
+        us[m & ((flags & 1) == 0)].mean() if (m & ((flags & 1) == 0)).any() else 0.0))
 top = np.argsort(-us)[:8]
 tx = (W + 7) // 8
 def tile_xy(t):   # the library numbers tiles by 8 x 8 blocks (rtx_kernel.hip: tile_xy)
