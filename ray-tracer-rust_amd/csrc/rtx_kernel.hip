@@ -1613,7 +1613,13 @@ namespace {
 
 // kSplitShare: a tile whose estimated cost is above this fraction of a workgroup's fair share of the launch is split
 // (the ablation build reads RTX_SPLIT_SHARE once instead: tools/share_timing.py sweeps it)
-constexpr float kSplitShare = 0.5f;
+// (50 until the estimates learned to tell the tiles apart — the probing walk of cut tiles, mixed tiles twice; with them
+//  a whole fair share: big_bunny 1080p 0.855 -> 0.825 ms over five interleaved rounds, one share of 4 / 8 -1.3 / -0.4 %,
+//  of 2 +0.8 %; profiles/r03/xh_ab_split_share.log)
+#ifndef RTX_SPLIT_SHARE_PERCENT
+#define RTX_SPLIT_SHARE_PERCENT 100
+#endif
+constexpr float kSplitShare = RTX_SPLIT_SHARE_PERCENT * 0.01f;
 float split_share()
 {
 #if RTX_ABLATION
@@ -1799,7 +1805,7 @@ extern "C" __attribute__((used, visibility("hidden"))) const char rtx_build_swit
     RTX_SW(RTX_PACKED_WAVES_PER_SIMD) RTX_SW(RTX_KEEP_PROBING_WALK) RTX_SW(RTX_PLANE_SHORTCUT) RTX_SW(RTX_PRIMARY_STREAM) RTX_SW(RTX_PROBE_CUT_TILES) RTX_SW(RTX_PROBE_MIX) RTX_SW(RTX_PROBE_VISIT_SCALE) RTX_SW(RTX_PROBE_WAVES) RTX_SW(RTX_PROBE_WAVES_PER_SIMD)
     RTX_SW(RTX_PROBE_WIDE) RTX_SW(RTX_PROBE_XCD) RTX_SW(RTX_SHADE_CUT_WAVES_PER_SIMD) RTX_SW(RTX_WHOLE_DRAW_CHUNKS)
     RTX_SW(RTX_SHADE_LEAN_STEP) RTX_SW(RTX_SHADE_NW) RTX_SW(RTX_SHADE_PRIORITY)
-    RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN)
+    RTX_SW(RTX_SHADE_WAVES_PER_SIMD) RTX_SW(RTX_SKIP_ROOT_TEST) RTX_SW(RTX_SPLIT_SCALE_MIN) RTX_SW(RTX_SPLIT_SHARE_PERCENT)
     RTX_SW(RTX_TILE_BLOCKS) RTX_SW(RTX_TILE_PARTS_MAX) RTX_SW(RTX_TRIANGLE_EARLY_OUT)
     RTX_SW(RTX_TRI_BOX_FIRST) RTX_SW(RTX_TRI_TOUCH_NEXT) RTX_SW(RTX_WALK_INTEGER_FLAGS) RTX_SW(RTX_WALK_SINGLE_EXIT)
     RTX_SW(RTX_WAVES_PER_SIMD) RTX_SW(RTX_WIDE_WALK) RTX_SW(RTX_XCD_QUEUES)
