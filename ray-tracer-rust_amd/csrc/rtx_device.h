@@ -81,7 +81,7 @@ constexpr uint32_t kCutWords = sizeof(CutEntry) / 4u;
 #ifndef RTX_MAX_CUT
 #define RTX_MAX_CUT 16
 #endif
-#define RTX_MAX_CUT_VALUE static_cast<size_t>(RTX_MAX_CUT)
+constexpr uint32_t kMaxCut = RTX_MAX_CUT;
 struct StreamWorkspace {
     HitRec   *hits;      // one per primary hit, compacted per tile
     uint32_t *pix_slot;  // tiles x 64: hit record of the pixel, or 0xFFFFFFFF
@@ -91,8 +91,9 @@ struct StreamWorkspace {
     float    *acc;       // tiles x 64 x 3 running sums, only when nb_ray > 1
     uint32_t *ctr;       // hit count, chunk count, chunk cursor
     uint32_t *buckets;   // probe pipeline: tile order by cost class (layout: order_tiles_kernel)
-    CutEntry *cut;       // tiles x kMaxCut: the subtrees the tile's shaft towards the light can touch — written by
-                         // probe_kernel, walked by shade_tiles_kernel
+    CutEntry *cut;       // tiles x kMaxCut entries (A/B forms; the whole-stream form keeps two words of answers in a tile's
+                         // first entry), then — cut_stream_offset — tiles x kCutStreamRecords node records: the tiles' cuts
+                         // as streams; written by probe_kernel, walked by shade_tiles_kernel
 };
 // Behind the tiles' CutEntry arrays, in the same buffer: every tile's cut once more AS A STREAM — kMaxCut node records of
 // 32 bytes that the shading pass steps with the walk's own box step (rtx_traverse.hpp: walk_cut_stream): a real leaf's record
@@ -101,16 +102,15 @@ struct StreamWorkspace {
 // A tile's stream has kMaxCut + 1 records: the last one holds the box around ALL of the cut's roots (a chunk whose rays
 // all miss it — most chunks that find no occluder — tests nothing else).
 constexpr uint32_t kCutInnerFlag = 1u << 29, kCutEndMask = (1u << 26) - 1u;
-constexpr uint32_t kCutStreamRecords = RTX_MAX_CUT + 1u;
-__host__ __device__ inline size_t cut_stream_offset(size_t tiles) { return (tiles * RTX_MAX_CUT_VALUE * 40u + 63u) & ~static_cast<size_t>(63u); }
+constexpr uint32_t kCutStreamRecords = kMaxCut + 1u;
+__host__ __device__ inline size_t cut_stream_offset(size_t tiles)      // bytes from StreamWorkspace::cut to the first stream
+{
+    return (tiles * kMaxCut * sizeof(CutEntry) + 63u) & ~static_cast<size_t>(63u);
+}
 struct StreamWorkspaceBytes { size_t hits, pix_slot, tiles, chunks, results, acc, ctr, buckets, cut; };
-#ifndef RTX_MAX_CUT
-#define RTX_MAX_CUT 16
-#endif
 // 1: the kernels walk the four-child form of the tree (rtx_traverse.hpp: walk_wide) instead of the binary stream.  Same
 // bytes, measured slower on every configuration: kept as a build switch for A/B runs only.
 // (RTX_WIDE_WALK: default 0 in scene_prep.h, which also decides whether the four-child tree is built at all)
-constexpr uint32_t kMaxCut = RTX_MAX_CUT;
 // Supported range of the A/B switch.  Above: a job stages its tile's cut with ONE word per work-item of its 512
 // (rtx_kernel.hip: cut_word), so kCutWords * kMaxCut <= 512 — the build of round 2's cut-size sweep that printed no bench
 // line (profiles/r02/h_ab_cut_size_with_roots_in_lds.log, "build 5" = 64 entries of the ten-word CutEntry = 640 words) left
