@@ -515,8 +515,11 @@ __device__ __forceinline__ bool length_and_direction(float vx, float vy, float v
 // records one after another, each a dependent fetch of a line of its own, and in a scene whose records do not fit the
 // L2s (BASELINE configs[4]) each of them is a miss of several hundred cycles; this way the next one is on its way — into
 // L2 and the scalar cache — while the current one is tested.  The array has one spare record at its end (rtx_api.cpp).
+// (It paid -1 % on the 1M-triangle soup when it went in; since the primitive record's own box is tested first it costs
+//  1.4 % there — the box test leaves the next fetch less to hide behind — and nothing on the OBJ scenes: off.
+//  profiles/r03/xj_ab_older_switches_again.log)
 #ifndef RTX_TRI_TOUCH_NEXT
-#define RTX_TRI_TOUCH_NEXT 1
+#define RTX_TRI_TOUCH_NEXT 0
 #endif
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ TriRec load_tri_at(const TriRec RTX_CONSTANT *base, uint32_t index)
